@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: GStencil/s (lattice updates/s) of the 7-pt fp64 brick sweep, 512^3 per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N = 1  workload "single-7pt-512": the reference's single/hip d3pt7 `Trans` launch (stencils/3axis.hip.cpp:165-171):
+       lexicographic 66^3 brick grid, in/out interleaved in one storage (step 1024), 7pt.py coefficients,
+       one step = one sweep over the 64^3 interior bricks.
+N > 1  workload "weak-7pt-512": weak/main.cu shape: BrickDecomp 512^3 per rank on a periodic MPI_Dims_create(N) grid,
+       one step = one brick_func = ghost exchange (RCCL send/recv + device links) overlapped with the inner bricks'
+       first sweep, then ST_ITER = 8 sweeps in all.  GStencil/s counts useful updates only (weak/main.cpp:285-287).
+Prints ONE JSON line on rank 0.  Inputs are synthetic U[0,1) already resident in HBM when timing starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0
+BYTES_PER_UPDATE = 16.0        # one fp64 read + one fp64 write per lattice update
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--n", type=int, default=512, help="cells per axis per GPU (default 512 = BASELINE config)")
+    ap.add_argument("--stencil", default=None, help="override stencil (7pt|27pt|mpi7pt|mpi13pt|mpi25pt|mpi125pt)")
+    ap.add_argument("--workload", default=None, choices=[None, "single", "weak"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def verify_sample(bl, O, sid, info, st_in, st_out, step, off_out, ids, coeff, nsample=2048, seed=5):
+    """size-independent spot check at full size: `nsample` random bricks of the sweep vs the CPU oracle."""
+    rng = np.random.default_rng(seed)
+    sub = np.sort(rng.choice(ids, size=min(nsample, ids.size), replace=False)).astype(np.uint32)
+    hin = st_in.dat.cpu().numpy().reshape(-1, step)
+    fin = np.ascontiguousarray(hin[:, :512]).reshape(-1) if step != 512 else hin.reshape(-1)
+    want = np.zeros_like(fin)
+    O.brick_stencil(sid, info.adj_host, fin, want, 512, ids=sub, coeff=coeff)
+    got = st_out.dat.cpu().numpy().reshape(-1, step)[sub, off_out:off_out + 512]
+    return float(np.abs(got - want.reshape(-1, 512)[sub]).max())
+
+
+def cpu_baseline(O, sid, info, st, step, ids, coeff, n_cells, seconds):
+    """The oracle (CPU restatement, OpenMP over bricks) on the same sweep, all host cores, ~`seconds` of work."""
+    hin = st.dat.cpu().numpy().reshape(-1, step)
+    fin = np.ascontiguousarray(hin[:, :512]).reshape(-1) if step != 512 else hin.reshape(-1)
+    out = np.zeros_like(fin)
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    O.brick_stencil(sid, info.adj_host, fin, out, 512, ids=ids, coeff=coeff)   # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        O.brick_stencil(sid, info.adj_host, fin, out, 512, ids=ids, coeff=coeff)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    cores = len(os.sched_getaffinity(0))
+    return {"value": n_cells * reps / dt / 1e9, "unit": "GStencil/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} full sweeps of the same {round(n_cells ** (1 / 3))}^3 brick list with oracle/brick_oracle.c "
+                      f"(OpenMP, {cores} threads), {dt:.1f} s"}
+
+
+def run_single(args, bl, dev):
+    from bricklib_amd.brick import grid_to_device
+    from bricklib_amd.stencils import STENCILS
+    N = args.n
+    name = args.stencil or "7pt"
+    sid = STENCILS[name]
+    K = args.steps if args.steps is not None else 200
+    W = args.warmup if args.warmup is not None else 20
+    SB = (N + 16) // 8
+    grid, info = bl.init_grid((SB, SB, SB), dev)
+    st = bl.BrickStorage.allocate(info.nbricks, 1024, dev)
+    st.dat.uniform_(0.0, 1.0)
+    bIn, bOut = bl.Brick(info, st, 0), bl.Brick(info, st, 512)
+    ids = np.ascontiguousarray(grid.reshape(SB, SB, SB)[1:-1, 1:-1, 1:-1]).reshape(-1)
+    ids_dev = grid_to_device(ids, dev)
+    rng = np.random.default_rng(1)
+    coeff = rng.random(129) if name in ("7pt", "27pt") else None
+    stream = torch.cuda.current_stream()
+
+    def step():
+        bl.apply_stencil(sid, bIn, bOut, ids=ids_dev, coeff=coeff, stream=stream)
+
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(K):
+        step()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1) / K
+    cells = float(N) ** 3
+    res = {"workload": f"single-{name}-{N}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+           "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
+           "kernel": "k_star/k_cube<%s> over %d bricks" % (name, ids.size)}
+    extra = {}
+    try:
+        from oracle.oracle import Oracle
+        O = Oracle()
+        extra["max_abs_err_vs_oracle"] = verify_sample(bl, O, sid, info, st, st, 1024, 512, ids, coeff)
+        if not args.no_cpu_baseline:
+            extra["cpu_baseline"] = cpu_baseline(O, sid, info, st, 1024, ids, coeff, cells, args.cpu_seconds)
+    except Exception as e:  # the checker is optional for the measurement itself
+        extra["oracle_error"] = repr(e)
+    return res, extra
+
+
+def run_weak(args, bl, dev, rank, world):
+    import torch.distributed as dist
+    from bricklib_amd.decomp import Exchanger, rank_to_coo
+    from bricklib_amd.drivers import weak_cycle
+    from bricklib_amd.stencils import STENCILS
+    N = args.n
+    name = args.stencil or "mpi7pt"
+    sid = STENCILS[name]
+    K = args.steps if args.steps is not None else 25
+    W = args.warmup if args.warmup is not None else 3
+    cart = bl.dims_create(world)
+    d = bl.BrickDecomp((N, N, N), 8)
+    bl.populate(d, cart, rank_to_coo(rank, cart))
+    info = d.getBrickInfo(dev)
+    stA, stB = info.allocate(512, dev), info.allocate(512, dev)
+    stA.dat.uniform_(0.0, 1.0)
+    A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
+    ex = Exchanger(d, stA, rank)
+    main = torch.cuda.current_stream()
+    comm = torch.cuda.Stream()
+    overlap = not args.no_overlap
+
+    def step():
+        return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=comm, overlap=overlap)
+
+    S = bl.stencil_iters(sid)
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(main)
+    for _ in range(K):
+        step()
+    e1.record(main)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    cells = float(N) ** 3 * S * world
+    res = {"workload": f"weak-{name}-{N}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+           "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,
+           "kernel": "k_star<%s> over brick ranges of BrickDecomp(%d^3): %d sweeps + 1 exchange per step" % (name, N, S),
+           "cart": cart, "overlap": overlap, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
+           "remote_bytes_per_rank": ex.bytes_remote}
+    return res, {}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import bricklib_amd as bl
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    workload = args.workload or ("single" if world == 1 else "weak")
+    if workload == "single":
+        res, extra = run_single(args, bl, dev)
+    else:
+        res, extra = run_weak(args, bl, dev, rank, world)
+    if rank == 0:
+        value = res["cells_per_step"] * res["K"] / res["wall"] / 1e9
+        ach = res["alg_bytes_per_launch"] / (res["kernel_ms"] * 1e-3) / 1e9
+        out = {
+            "metric": "GStencil/s", "value": value, "unit": "GStencil/s", "n_gpus": world, "steps": res["K"],
+            "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": args.n ** 3,
+                       **{k: res[k] for k in ("cart", "overlap", "exchange_bytes_per_rank", "remote_bytes_per_rank") if k in res}},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],
+                         "kernel_ms": res["kernel_ms"], "algorithmic_bytes_per_launch": res["alg_bytes_per_launch"]},
+        }
+        out.update(extra)
+        out.setdefault("cpu_baseline", None)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

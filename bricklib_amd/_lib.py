@@ -1,0 +1,105 @@
+"""ctypes binding of libbrk.so (C ABI: include/brk.h).  There is no fallback: if the HIP library has not
+been built (python -c 'import __graft_entry__ as g; g.build()'  or  make -C bricklib_amd/csrc) importing the
+package raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libbrk.so")
+
+BRK_7PT_COEFF, BRK_27PT_COEFF, BRK_MPI7, BRK_MPI13, BRK_MPI25, BRK_MPI125 = range(6)
+
+
+class BrkError(RuntimeError):
+    pass
+
+
+class Region(C.Structure):
+    """brk_region == g_region of include/brick-mpi.h:185-193"""
+    _fields_ = [("neighbor", C.c_uint64), ("skin_st", C.c_uint32), ("skin_ed", C.c_uint32), ("pos", C.c_uint32),
+                ("len", C.c_uint32), ("first_pad", C.c_uint32), ("last_pad", C.c_uint32)]
+
+
+class Link(C.Structure):
+    """brk_link"""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("bytes", C.c_uint64)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise BrkError(f"{LIB_PATH} is missing: the HIP extension must be built (make -C bricklib_amd/csrc); "
+                       "bricklib_amd has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u32p, f64p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+    L3 = C.c_long * 3
+    L.brk_last_error.restype = C.c_char_p
+    L.brk_abi_version.restype = C.c_int
+    for f in (L.brk_stencil_radius, L.brk_stencil_ncoeff, L.brk_stencil_iters):
+        f.argtypes = [C.c_int]
+        f.restype = C.c_int
+    L.brk_stencil_apply_range.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, f64p, vp]
+    L.brk_stencil_apply_list.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, vp, C.c_uint32, f64p, vp]
+    L.brk_set_variant.argtypes = [C.c_int, C.c_int]
+    L.brk_link_copy.argtypes = [vp, C.c_uint32, C.c_uint64, vp]
+    L.brk_array_to_brick.argtypes = [L3, L3, L3, vp, vp, vp, C.c_size_t, vp]
+    L.brk_brick_to_array.argtypes = [L3, L3, L3, vp, vp, vp, C.c_size_t, vp]
+    L.brk_compare_brick.argtypes = [L3, L3, L3, vp, vp, vp, C.c_size_t, C.c_double, vp, vp]
+    L.brk_init_grid.argtypes = [L3, u32p, u32p]
+    L.brk_decomp_build.argtypes = [C.c_uint32 * 3, C.c_uint32, C.POINTER(vp)]
+    L.brk_decomp_free.argtypes = [vp]
+    L.brk_decomp_free.restype = None
+    for name in ("nbricks", "grid_size", "nruns", "nskin"):
+        f = getattr(L, "brk_decomp_" + name)
+        f.argtypes = [vp]
+        f.restype = C.c_uint32
+    L.brk_decomp_tdims.argtypes = [vp, C.c_uint32 * 3]
+    L.brk_decomp_sep_pos.argtypes = [vp, C.c_uint32 * 3]
+    L.brk_decomp_grid.argtypes = [vp]
+    L.brk_decomp_grid.restype = u32p
+    L.brk_decomp_adj.argtypes = [vp]
+    L.brk_decomp_adj.restype = u32p
+    L.brk_decomp_ghost.argtypes = [vp]
+    L.brk_decomp_ghost.restype = C.POINTER(Region)
+    L.brk_decomp_skin.argtypes = [vp]
+    L.brk_decomp_skin.restype = C.POINTER(Region)
+    L.brk_decomp_skinlist.argtypes = [vp]
+    L.brk_decomp_skinlist.restype = C.POINTER(C.c_uint64)
+    L.brk_decomp_skin_size.argtypes = [vp]
+    L.brk_decomp_skin_size.restype = C.POINTER(C.c_int64)
+    L.brk_allneighbors3.argtypes = [C.c_uint64 * 27]
+    L.brk_allneighbors3.restype = None
+    L.brk_populate_rank_map.argtypes = [C.c_int * 3, C.c_int * 3, C.c_int * 27]
+    L.brk_dims_create.argtypes = [C.c_int, C.c_int * 3]
+    L.brk_zmort_get.argtypes = [C.c_uint64, C.c_uint64]
+    L.brk_zmort_get.restype = C.c_uint64
+    L.brk_zmort_set.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+    L.brk_zmort_set.restype = C.c_uint64
+    L.brk_strong_partition.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_uint64 * 2]
+    L.brk_strong_partition.restype = None
+    L.brk_strong_neighbor.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int),
+                                      C.POINTER(C.c_int)]
+    L.brk_strong_neighbor.restype = C.c_uint64
+    return L
+
+
+lib = _load()
+
+# every symbol include/brk.h declares (tests check the library exports each of them)
+ABI_SYMBOLS = [
+    "brk_last_error", "brk_abi_version", "brk_stencil_radius", "brk_stencil_ncoeff", "brk_stencil_iters",
+    "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_set_variant", "brk_link_copy", "brk_array_to_brick",
+    "brk_brick_to_array", "brk_compare_brick", "brk_init_grid", "brk_decomp_build", "brk_decomp_free",
+    "brk_decomp_nbricks", "brk_decomp_grid_size", "brk_decomp_tdims", "brk_decomp_sep_pos", "brk_decomp_grid",
+    "brk_decomp_adj", "brk_decomp_nruns", "brk_decomp_ghost", "brk_decomp_skin", "brk_decomp_nskin",
+    "brk_decomp_skinlist", "brk_decomp_skin_size", "brk_allneighbors3", "brk_populate_rank_map", "brk_dims_create",
+    "brk_zmort_get", "brk_zmort_set", "brk_strong_partition", "brk_strong_neighbor",
+]
+
+
+def check(rc):
+    if rc != 0:
+        raise BrkError(f"libbrk error {rc}: {lib.brk_last_error().decode()}")
+
+
+def l3(v):
+    return (C.c_long * 3)(*[int(x) for x in v])

@@ -1,0 +1,123 @@
+"""Brick data structures, mirroring include/brick.h, include/bricksetup.h, include/brickcompare.h and
+include/brick-gpu.h of the reference (names and argument meaning kept)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import check, l3, lib
+
+BRICK_TOLERANCE = 1e-6  # include/cmpconst.h:9
+BDIM = (8, 8, 8)
+BSIZE = 512
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(stream=None):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def _as_u32_tensor(a, device):
+    """uint32 host array -> int32 tensor with the same bits (ids < 2^31)."""
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return torch.from_numpy(a.view(np.int32).copy()).to(device)
+
+
+class BrickInfo:
+    """Adjacency list of a set of bricks (include/brick.h:96-127).  adj[b][(dk+1)*9+(dj+1)*3+(di+1)]."""
+
+    def __init__(self, adj, device=None):
+        if isinstance(adj, np.ndarray):
+            self.adj_host = np.ascontiguousarray(adj.reshape(-1, 27), dtype=np.uint32)
+            self.adj = None
+        else:
+            self.adj_host = None
+            self.adj = adj
+        self.nbricks = (self.adj_host if self.adj_host is not None else self.adj).shape[0]
+        if device is not None:
+            self.to(device)
+
+    def to(self, device):
+        if self.adj is None or self.adj.device != torch.device(device):
+            self.adj = _as_u32_tensor(self.adj_host, device).reshape(-1, 27)
+        return self
+
+    def allocate(self, step, device="cuda"):
+        return BrickStorage.allocate(self.nbricks, step, device)
+
+
+class BrickStorage:
+    """Flat storage of `chunks` chunks of `step` elements (include/brick.h:53-82)."""
+
+    def __init__(self, dat, chunks, step):
+        self.dat, self.chunks, self.step = dat, int(chunks), int(step)
+
+    @staticmethod
+    def allocate(chunks, step, device="cuda"):
+        return BrickStorage(torch.zeros(int(chunks) * int(step), dtype=torch.float64, device=device), chunks, step)
+
+
+class Brick:
+    """One field inside a BrickStorage (include/brick.h:353-395): brick b starts at dat[offset + b*step]."""
+
+    def __init__(self, bInfo, bStorage, offset=0):
+        self.bInfo, self.bStorage, self.offset = bInfo, bStorage, int(offset)
+        self.step = bStorage.step
+        self.dat = bStorage.dat[self.offset:]
+
+    def view(self):
+        """[nbricks, 8, 8, 8] strided view (k, j, i)."""
+        return torch.as_strided(self.dat, (self.bStorage.chunks, 8, 8, 8), (self.step, 64, 8, 1))
+
+
+def init_grid(dimlist, device=None):
+    """include/bricksetup.h:73-90 -> (grid uint32[size] host array, BrickInfo)."""
+    size = int(dimlist[0]) * int(dimlist[1]) * int(dimlist[2])
+    grid = np.empty(size, dtype=np.uint32)
+    adj = np.empty((size, 27), dtype=np.uint32)
+    check(lib.brk_init_grid(l3(dimlist), grid.ctypes.data_as(C.POINTER(C.c_uint32)),
+                            adj.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return grid, BrickInfo(adj, device)
+
+
+def movBrickInfo(bInfo, device="cuda"):
+    """include/brick-gpu.h:38-51"""
+    return BrickInfo(bInfo.adj_host, device)
+
+
+def movBrickStorage(bStorage, device="cuda"):
+    """include/brick-gpu.h:80-99"""
+    return BrickStorage(bStorage.dat.to(device), bStorage.chunks, bStorage.step)
+
+
+def grid_to_device(grid, device="cuda"):
+    return _as_u32_tensor(grid, device)
+
+
+def copyToBrick(dimlist, padding, ghost, arr, grid_dev, brick, stream=None):
+    """include/bricksetup.h:172-200 on device: arr (array layout, i contiguous) -> bricks."""
+    check(lib.brk_array_to_brick(l3(dimlist), l3(padding), l3(ghost), _ptr(arr), _ptr(grid_dev), _ptr(brick.dat),
+                                 brick.step, _stream(stream)))
+
+
+def copyFromBrick(dimlist, padding, ghost, arr, grid_dev, brick, stream=None):
+    """include/bricksetup.h:213-221 on device."""
+    check(lib.brk_brick_to_array(l3(dimlist), l3(padding), l3(ghost), _ptr(arr), _ptr(grid_dev), _ptr(brick.dat),
+                                 brick.step, _stream(stream)))
+
+
+def compareBrick(dimlist, padding, ghost, arr, grid_dev, brick, tol=BRICK_TOLERANCE, stream=None, return_max=False):
+    """include/brickcompare.h:30-57 on device -> True when every element matches under the reference rule."""
+    res = torch.zeros(2, dtype=torch.int64, device=brick.dat.device)
+    check(lib.brk_compare_brick(l3(dimlist), l3(padding), l3(ghost), _ptr(arr), _ptr(grid_dev), _ptr(brick.dat),
+                                brick.step, tol, _ptr(res), _stream(stream)))
+    r = res.cpu().numpy()
+    ok = int(r[0]) == 0
+    if return_max:
+        return ok, float(r[1:2].view(np.float64)[0])
+    return ok

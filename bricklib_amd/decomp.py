@@ -1,0 +1,188 @@
+"""BrickDecomp and ghost-zone exchange, mirroring include/brick-mpi.h of the reference.
+
+Layout tables (brick numbering, ghost/skin runs, adjacency) come from libbrk.so (brk_decomp_*).  The exchange
+keeps the reference rule -- ghost run i <- skin run i of the rank behind ghost[i].neighbor, every run a
+contiguous range of bricks so nothing is packed (include/brick-mpi.h:466-495) -- and moves the bytes
+  * with brk_link_copy (one HIP launch) for runs whose peer lives on this GPU (self-neighbours of 1/2/4-rank
+    periodic grids, or several virtual ranks on one GPU), and
+  * with grouped send/recv over torch.distributed (backend "nccl" = RCCL over xGMI) for real peers.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import Link, check, lib
+from .brick import BrickInfo, _stream
+
+
+def allneighbors():
+    """allneighbors(0,1,3,...) order of src/brick-mpi.cpp:9-23 as BitSet.set values; entry 13 is 0 (self)."""
+    out = (C.c_uint64 * 27)()
+    lib.brk_allneighbors3(out)
+    return [int(x) for x in out]
+
+
+def dims_create(size):
+    out = (C.c_int * 3)()
+    check(lib.brk_dims_create(int(size), out))
+    return [int(x) for x in out]
+
+
+def rank_to_coo(rank, cart_dims):
+    """row-major cart coordinates, as MPI_Cart_coords"""
+    c2 = rank % cart_dims[2]
+    c1 = (rank // cart_dims[2]) % cart_dims[1]
+    c0 = rank // (cart_dims[1] * cart_dims[2])
+    return [c0, c1, c2]
+
+
+def rank_origin(coo, cart_dims, dom):
+    """Global cell coordinate (i,j,k) of a rank's subdomain under populate()'s orientation: axis d lives in
+    coo[2-d] and the '+d' neighbour sits at coo-1 (include/brick-mpi.h:741-750), so positions decrease with coo."""
+    return [((cart_dims[2 - a] - coo[2 - a]) % cart_dims[2 - a]) * dom[a] for a in range(3)]
+
+
+class BrickDecomp:
+    """BrickDecomp<3,8,8,8>(dims, depth) + initialize(skin3d_good) (include/brick-mpi.h:178-460)."""
+
+    def __init__(self, dims, depth=8):
+        h = C.c_void_p()
+        check(lib.brk_decomp_build((C.c_uint32 * 3)(*[int(d) for d in dims]), int(depth), C.byref(h)))
+        self._h = h
+        self.dims = [int(d) for d in dims]
+        self.depth = int(depth)
+        self.nbricks = lib.brk_decomp_nbricks(h)
+        t = (C.c_uint32 * 3)()
+        lib.brk_decomp_tdims(h, t)
+        self.t_dims = [int(x) for x in t]
+        s = (C.c_uint32 * 3)()
+        lib.brk_decomp_sep_pos(h, s)
+        self.sep_pos = [int(x) for x in s]
+        gs = lib.brk_decomp_grid_size(h)
+        self.grid = np.ctypeslib.as_array(lib.brk_decomp_grid(h), shape=(gs,)).copy().reshape(self.t_dims[2], self.t_dims[1],
+                                                                                              self.t_dims[0])
+        self.adj = np.ctypeslib.as_array(lib.brk_decomp_adj(h), shape=(self.nbricks * 27,)).copy().reshape(-1, 27)
+        nr = lib.brk_decomp_nruns(h)
+        g, k = lib.brk_decomp_ghost(h), lib.brk_decomp_skin(h)
+        fields = ("neighbor", "skin_st", "skin_ed", "pos", "len", "first_pad", "last_pad")
+        self.ghost = [{f: int(getattr(g[q], f)) for f in fields} for q in range(nr)]
+        self.skin = [{f: int(getattr(k[q], f)) for f in fields} for q in range(nr)]
+        ns = lib.brk_decomp_nskin(h)
+        self.skinlist = [int(lib.brk_decomp_skinlist(h)[q]) for q in range(ns)]
+        self.skin_size = [int(lib.brk_decomp_skin_size(h)[q]) for q in range(ns)]
+        self.rank_map = {}   # BitSet.set -> rank, filled by populate()
+
+    def __del__(self):
+        try:
+            lib.brk_decomp_free(self._h)
+        except Exception:
+            pass
+
+    def __getitem__(self, k):
+        return self.grid[k]
+
+    def getBrickInfo(self, device=None):
+        return BrickInfo(self.adj, device)
+
+    def runs_table(self, which="ghost"):
+        f = ("neighbor", "skin_st", "skin_ed", "pos", "len", "first_pad", "last_pad")
+        src = self.ghost if which == "ghost" else self.skin
+        return np.array([[r[x] for x in f] for r in src], dtype=np.uint64)
+
+
+def populate(bDecomp, cart_dims, coo):
+    """populate(comm, bDecomp, 0, 1, coo) of include/brick-mpi.h:730-753 for a periodic cart grid."""
+    out = (C.c_int * 27)()
+    check(lib.brk_populate_rank_map((C.c_int * 3)(*cart_dims), (C.c_int * 3)(*coo), out))
+    bDecomp.rank_map = {n: int(out[q]) for q, n in enumerate(allneighbors())}
+    return bDecomp.rank_map
+
+
+class LinkTable:
+    """Device-resident brk_link table + its launch parameters."""
+
+    def __init__(self, links, device):
+        # links: list of (src_ptr, dst_ptr, bytes)
+        self.n = len(links)
+        self.max_bytes = max([b for _, _, b in links], default=0)
+        self.total_bytes = sum(b for _, _, b in links)
+        arr = (Link * max(self.n, 1))()
+        for q, (s, d, b) in enumerate(links):
+            arr[q].src, arr[q].dst, arr[q].bytes = s, d, b
+        host = np.frombuffer(bytes(arr), dtype=np.int64).copy()
+        self.dev = torch.from_numpy(host).to(device)
+
+    def run(self, stream=None):
+        if self.n:
+            check(lib.brk_link_copy(C.c_void_p(self.dev.data_ptr()), self.n, self.max_bytes, _stream(stream)))
+
+
+def local_links(bDecomp, storages, rank_maps, ranks):
+    """Links for every ghost run whose source rank is in `ranks` (dict rank -> BrickStorage on this GPU).
+    rank_maps: dict rank -> {BitSet.set -> rank}.  Returns (links, remote) where remote lists the runs that need
+    a real transport as (rank, run index, src rank)."""
+    links, remote = [], []
+    for r, st in storages.items():
+        esz = st.dat.element_size()
+        for q, (g, s) in enumerate(zip(bDecomp.ghost, bDecomp.skin)):
+            src_rank = rank_maps[r][g["neighbor"]]
+            if src_rank in ranks:
+                src = storages[src_rank]
+                links.append((src.dat.data_ptr() + s["pos"] * src.step * esz, st.dat.data_ptr() + g["pos"] * st.step * esz,
+                              g["len"] * st.step * esz))
+            else:
+                remote.append((r, q, src_rank))
+    return links, remote
+
+
+class Exchanger:
+    """Ghost exchange of ONE rank's storage (the `ev.exchange()` / `bDecomp.exchange(bStorage)` call of
+    weak/main.cpp:172-183).  Self-neighbour runs become device links; the rest are grouped P2P ops."""
+
+    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False):
+        self.d, self.st, self.rank, self.group = bDecomp, storage, rank, group
+        self.cpu = storage.dat.device.type == "cpu"
+        if self.cpu and not allow_cpu_plumbing:
+            raise RuntimeError("Exchanger on CPU tensors is test plumbing only (gloo); pass allow_cpu_plumbing=True")
+        links, remote = local_links(bDecomp, {rank: storage}, {rank: bDecomp.rank_map}, {rank})
+        self._cpu_links = []
+        if self.cpu:
+            step = storage.step
+            for g, s in zip(bDecomp.ghost, bDecomp.skin):
+                if bDecomp.rank_map[g["neighbor"]] == rank:
+                    self._cpu_links.append((g["pos"] * step, s["pos"] * step, g["len"] * step))
+            self.table = None
+        else:
+            self.table = LinkTable(links, storage.dat.device)
+        self.remote = [(q, src) for _, q, src in remote]
+        self.bytes_remote = sum(bDecomp.ghost[q]["len"] for q, _ in self.remote) * storage.step * 8
+
+    def _ops(self):
+        import torch.distributed as dist
+        step, dat, ops = self.st.step, self.st.dat, []
+        for q, src in self.remote:   # same run order on every rank: pairwise matching is by issue order
+            g, s = self.d.ghost[q], self.d.skin[q]
+            dst = self.d.rank_map[s["neighbor"]]
+            ops.append(dist.P2POp(dist.irecv, dat[g["pos"] * step:(g["pos"] + g["len"]) * step], src, self.group))
+            ops.append(dist.P2POp(dist.isend, dat[s["pos"] * step:(s["pos"] + s["len"]) * step], dst, self.group))
+        return ops
+
+    def exchange(self, stream=None):
+        """Asynchronous on `stream` (default: current stream) for device storages."""
+        if self.cpu:
+            for dpos, spos, n in self._cpu_links:
+                self.st.dat[dpos:dpos + n] = self.st.dat[spos:spos + n].clone()
+        else:
+            self.table.run(stream)
+        if self.remote:
+            import torch.distributed as dist
+            if self.cpu or stream is None:
+                reqs = dist.batch_isend_irecv(self._ops())
+                for r in reqs:
+                    r.wait()
+            else:
+                with torch.cuda.stream(stream):
+                    reqs = dist.batch_isend_irecv(self._ops())
+                    for r in reqs:
+                        r.wait()

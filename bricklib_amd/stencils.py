@@ -1,0 +1,42 @@
+"""Stencil apply -- the hot path.  Python face of brk_stencil_apply_{range,list} (include/brk.h)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import (BRK_7PT_COEFF, BRK_27PT_COEFF, BRK_MPI7, BRK_MPI13, BRK_MPI25, BRK_MPI125, check, lib)
+from .brick import _ptr, _stream
+
+# name -> id; names follow the reference's stencil scripts (stencils/*.py) and drivers
+STENCILS = {"7pt": BRK_7PT_COEFF, "27pt": BRK_27PT_COEFF, "mpi7pt": BRK_MPI7, "mpi13pt": BRK_MPI13,
+            "mpi25pt": BRK_MPI25, "mpi125pt": BRK_MPI125}
+
+
+def _sid(stencil):
+    return STENCILS[stencil] if isinstance(stencil, str) else int(stencil)
+
+
+def stencil_radius(stencil):
+    return lib.brk_stencil_radius(_sid(stencil))
+
+
+def stencil_iters(stencil):
+    """ST_ITER of stencils/fake.h: sweeps per ghost exchange."""
+    return lib.brk_stencil_iters(_sid(stencil))
+
+
+def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, coeff=None, stream=None):
+    """out[b] = stencil(in[b], neighbours) for b in `ids` (device int32 tensor holding uint32 brick ids, e.g.
+    the reference's `grid`) or in brick_range=(begin,end).  bIn/bOut: Brick objects sharing one BrickInfo."""
+    sid = _sid(stencil)
+    cp = None
+    if coeff is not None:
+        cbuf = np.ascontiguousarray(coeff, dtype=np.float64)
+        cp = cbuf.ctypes.data_as(C.POINTER(C.c_double))
+    adj = bIn.bInfo.adj
+    if ids is not None:
+        check(lib.brk_stencil_apply_list(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids),
+                                         ids.numel(), cp, _stream(stream)))
+    else:
+        b0, b1 = brick_range if brick_range is not None else (0, bIn.bInfo.nbricks)
+        check(lib.brk_stencil_apply_range(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, int(b0), int(b1), cp,
+                                          _stream(stream)))

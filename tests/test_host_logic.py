@@ -1,0 +1,119 @@
+"""CPU-side checks of the product's host logic (libbrk.so layout builders) against the pinned oracle and the
+golden fixtures, plus: the C-ABI library loads and exports every symbol include/brk.h declares."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bricklib_amd as bl
+from bricklib_amd._lib import ABI_SYMBOLS, LIB_PATH, lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "brk.h")).read()
+    declared = set(re.findall(r"\b(brk_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
+    L = C.CDLL(LIB_PATH)
+    for s in ABI_SYMBOLS:
+        assert hasattr(L, s), s
+    assert lib.brk_abi_version() == 1000
+
+
+def test_error_convention():
+    rc = lib.brk_stencil_apply_range(99, None, None, None, 512, 0, 1, None, None)
+    assert rc == -1 and b"stencil" in lib.brk_last_error()
+    with pytest.raises(bl.BrkError):
+        bl.BrickDecomp((20, 16, 16))          # not a multiple of the brick edge
+    assert lib.brk_stencil_radius(bl.BRK_MPI25) == 4 and lib.brk_stencil_iters(bl.BRK_MPI13) == 4
+    assert lib.brk_stencil_ncoeff(bl.BRK_MPI125) == 10
+
+
+@pytest.mark.parametrize("dims", [(4, 4, 4), (6, 5, 4)])
+def test_init_grid_golden(golden, dims):
+    z = golden("init_grid_%dx%dx%d" % dims)
+    grid, info = bl.init_grid(dims)
+    assert (grid == z["grid"]).all() and (info.adj_host == z["adj"]).all()
+
+
+@pytest.mark.parametrize("dims", [(16, 16, 16), (32, 32, 32), (24, 32, 40), (64, 64, 64)])
+def test_decomp_golden(golden, dims):
+    z = golden("decomp_%dx%dx%d" % dims)
+    d = bl.BrickDecomp(dims, 8)
+    assert d.sep_pos == [int(x) for x in z["sep_pos"]] and d.nbricks == int(z["nbricks"][0])
+    assert (d.grid.reshape(-1) == z["grid"]).all()
+    assert (d.adj[1:] == z["adj_from1"]).all() and (d.adj[0] == 0).all()
+    assert (np.array(d.skin_size) == z["skin_size"]).all()
+    assert (d.runs_table("ghost") == z["ghost"]).all() and (d.runs_table("skin") == z["skin"]).all()
+
+
+def test_decomp_512_matches_survey_appendix_a(oracle):
+    d = bl.BrickDecomp((512, 512, 512), 8)
+    o = oracle.decomp((512, 512, 512))
+    assert d.sep_pos == [238329, 262145, 287497] and len(d.ghost) == 42
+    assert (d.grid.reshape(-1) == o.grid).all() and (d.adj == o.adj).all()
+    assert sum(g["len"] for g in d.ghost) * 4096 == 103841792
+
+
+def test_neighbors_rank_maps_dims(oracle, golden):
+    z = golden("bitset_zmort")
+    assert bl.allneighbors() == [int(x) for x in z["allneighbors"]]
+    d = bl.BrickDecomp((16, 16, 16))
+    assert d.skinlist == [int(x) for x in z["skin3d_good"]]
+    for size in (1, 2, 4, 8, 6, 12):
+        cart = bl.dims_create(size)
+        assert cart[0] * cart[1] * cart[2] == size and cart[0] >= cart[1] >= cart[2]
+        for rank in range(size):
+            coo = bl.decomp.rank_to_coo(rank, cart)
+            rm = bl.populate(d, cart, coo)
+            want = oracle.populate_rank_map(cart, coo)
+            assert [rm[n] for n in bl.allneighbors()] == [int(x) for x in want]
+            assert rm[0] == rank
+    assert bl.dims_create(8) == [2, 2, 2] and bl.dims_create(4) == [2, 2, 1] and bl.dims_create(2) == [2, 1, 1]
+
+
+def test_rank_map_symmetry():
+    """receiver/sender agreement needed by the exchange: map_R[n] == S  <=>  map_S[!n] == R"""
+    d = bl.BrickDecomp((16, 16, 16))
+    neg = {g["neighbor"]: s["neighbor"] for g, s in zip(d.ghost, d.skin)}
+    for size in (2, 4, 8, 12):
+        cart = bl.dims_create(size)
+        maps = [dict(bl.populate(d, cart, bl.decomp.rank_to_coo(r, cart))) for r in range(size)]
+        for r in range(size):
+            for n, nn in neg.items():
+                assert maps[maps[r][n]][nn] == r
+
+
+def test_zmort_and_strong_partition(oracle, golden):
+    z = golden("bitset_zmort")
+    for (zid, d, p), g, s in zip(z["zq"], z["zget"], z["zset"]):
+        assert lib.brk_zmort_get(int(zid), int(d)) == int(g)
+        assert lib.brk_zmort_set(int(zid), int(d), int(p)) == int(s)
+    for subdim, size in ((2, 4), (4, 8), (4, 3), (8, 8), (4, 5)):
+        allsubs = subdim ** 3
+        cover = []
+        for rank in range(size):
+            lr = (C.c_uint64 * 2)()
+            lib.brk_strong_partition(allsubs, size, rank, lr)
+            want = oracle.strong_partition(allsubs, size, rank)
+            assert [int(lr[0]), int(lr[1])] == want[:2]
+            cover += list(range(int(lr[0]), int(lr[1])))
+        assert cover == list(range(allsubs))
+        for n in bl.allneighbors():
+            for zid in range(0, allsubs, 3):
+                o, s = C.c_int(), C.c_int()
+                nz = lib.brk_strong_neighbor(n, zid, subdim, allsubs, size, C.byref(o), C.byref(s))
+                assert (int(nz), o.value, s.value) == oracle.strong_getrank(n, zid, subdim, size)
+
+
+def test_exchange_plan_covers_ghost_once():
+    d = bl.BrickDecomp((32, 32, 32))
+    covered = np.zeros(d.nbricks, dtype=np.int32)
+    for g in d.ghost:
+        covered[g["pos"]:g["pos"] + g["len"]] += 1
+    assert (covered[d.sep_pos[1]:d.sep_pos[2]] == 1).all() and covered[:d.sep_pos[1]].sum() == 0
+    for s in d.skin:
+        assert d.sep_pos[0] <= s["pos"] and s["pos"] + s["len"] <= d.sep_pos[1]
