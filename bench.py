@@ -90,7 +90,9 @@ def run_single(args, bl, dev):
     st = bl.BrickStorage.allocate(info.nbricks, 1024, dev)
     st.dat.uniform_(0.0, 1.0)
     bIn, bOut = bl.Brick(info, st, 0), bl.Brick(info, st, 512)
-    ids = np.ascontiguousarray(grid.reshape(SB, SB, SB)[1:-1, 1:-1, 1:-1]).reshape(-1)
+    from bricklib_amd.order import tiled
+    # same bricks as the reference launch `b = grid[tk][tj][ti]` (3axis.hip.cpp:36-39); only the traversal order is ours
+    ids = tiled(grid.reshape(SB, SB, SB)[1:-1, 1:-1, 1:-1])
     ids_dev = grid_to_device(ids, dev)
     rng = np.random.default_rng(1)
     coeff = rng.random(129) if name in ("7pt", "27pt") else None
@@ -145,12 +147,14 @@ def run_weak(args, bl, dev, rank, world):
     stA.dat.uniform_(0.0, 1.0)
     A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
     ex = Exchanger(d, stA, rank)
+    from bricklib_amd.drivers import SweepLists
+    lists = SweepLists(d, dev)
     main = torch.cuda.current_stream()
     comm = torch.cuda.Stream()
     overlap = not args.no_overlap
 
     def step():
-        return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=comm, overlap=overlap)
+        return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=comm, overlap=overlap, lists=lists)
 
     S = bl.stencil_iters(sid)
     for _ in range(W):

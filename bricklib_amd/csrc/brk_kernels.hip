@@ -11,38 +11,13 @@
 //     block id is remapped to give each XCD one contiguous eighth of the list; consecutive bricks (which share
 //     faces) then meet in the same 4 MiB L2.
 // HBM-bound by design: 16 B of compulsory traffic per lattice update, no MFMA (not a contraction).
-#include <hip/hip_runtime.h>
-
-#include <cstdint>
 #include <cstring>
 
-#include "brk_internal.h"
+#include "brk_device.h"
+
+using namespace brk;
 
 namespace {
-
-constexpr int kWavesPerWG = 4;
-constexpr int kWG = 64 * kWavesPerWG;
-
-struct Coeffs {
-  double c[32];
-};
-
-#define HIP_TRY(expr)                                                                             \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess) return brk_fail(BRK_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-
-// adjacency slot of direction (dk,dj,di), include/brick.h:237-245
-__host__ __device__ constexpr int adj_slot(int dk, int dj, int di) { return (dk + 1) * 9 + (dj + 1) * 3 + (di + 1); }
-
-// Wave-local LDS ordering.  The hardware runs one wave's DS instructions in order; these only stop the
-// compiler from moving a lane's reads above other lanes' writes.
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Which entry of the brick list this wave owns (or n if none).  XCD-aware: see file header.
 __device__ __forceinline__ uint32_t wave_slot(uint32_t n) {
@@ -408,6 +383,7 @@ __global__ __launch_bounds__(kWG) void k_iter(IterGeom g, double *__restrict__ a
 }
 
 int g_variant[BRK_NSTENCIL] = {0, 0, 0, 0, 0, 0};
+constexpr int kDefaultStar7Variant = 5; // 8-wave workgroups sharing i-faces through LDS (brk_star7.hip)
 
 // defaults: stencils/fake.h:11-33
 const double kDefault[BRK_NSTENCIL][10] = {{0}, {0}, {0.4, 0.1}, {0.4, 0.07, 0.03}, {0.1, 0.06, 0.045, 0.03, 0.015},
@@ -446,6 +422,9 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   const uint32_t wgs = (n + kWavesPerWG - 1) / kWavesPerWG;
   const dim3 grid(((wgs + 7) / 8) * 8), block(kWG);
   hipStream_t st = static_cast<hipStream_t>(s);
+  // 7-point sweeps: specialised kernels (brk_star7.hip) unless variant 1 (generic star kernel) is requested
+  if ((id == BRK_7PT_COEFF || id == BRK_MPI7) && g_variant[id] != 1)
+    return launch_star7(id, g_variant[id] == 0 ? kDefaultStar7Variant : g_variant[id], adj, in, out, step, ids, first, n, cf, st);
   switch (id) {
   case BRK_7PT_COEFF: hipLaunchKernelGGL(k_star<kStar7Coeff>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_MPI7: hipLaunchKernelGGL(k_star<kStarMpi7>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;

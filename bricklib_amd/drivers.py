@@ -9,19 +9,38 @@ the region ordering of BrickDecomp the three brick sets involved are plain id ra
 """
 import torch
 
+from .brick import grid_to_device
+from .order import decomp_lists
 from .stencils import apply_stencil, stencil_iters
 
 
-def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, overlap=True):
+class SweepLists:
+    """Device-resident brick lists of one BrickDecomp for the sweep schedule (same brick sets as the id ranges in
+    the module docstring, but in the cache-friendly order of bricklib_amd.order)."""
+
+    def __init__(self, d, device, rows_per_block=8):
+        for name, ids in decomp_lists(d, rows_per_block).items():
+            setattr(self, name, grid_to_device(ids, device))
+
+
+def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, overlap=True, lists=None):
     """A, B: Brick objects over two storages built from decomposition `d`; exchange(stream) refreshes A's ghosts.
-    main/comm: torch streams (default: current stream, no overlap)."""
+    main/comm: torch streams (default: current stream, no overlap).  lists: SweepLists(d) (optional; without it the
+    sweeps run over plain id ranges)."""
     S = stencil_iters(stencil)
     sep0, sep1, sep2 = d.sep_pos
     main = main or torch.cuda.current_stream()
+
+    def sweep(src, dst, which):
+        if lists is not None:
+            apply_stencil(stencil, src, dst, ids=getattr(lists, which), coeff=coeff, stream=main)
+        else:
+            rng = {"inner": (1, sep0), "shell": (sep0, sep2), "all": (1, sep2), "domain": (1, sep1)}[which]
+            apply_stencil(stencil, src, dst, brick_range=rng, coeff=coeff, stream=main)
+
     if comm is None or not overlap:
         exchange(main)
-        with torch.cuda.stream(main):
-            apply_stencil(stencil, A, B, brick_range=(1, sep2), coeff=coeff, stream=main)
+        sweep(A, B, "all")
     else:
         ev0 = torch.cuda.Event()
         ev0.record(main)                 # A as left by the previous cycle
@@ -29,11 +48,11 @@ def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, ove
         exchange(comm)                   # ghosts of A arrive on the comm stream ...
         ev1 = torch.cuda.Event()
         ev1.record(comm)
-        apply_stencil(stencil, A, B, brick_range=(1, sep0), coeff=coeff, stream=main)   # ... while the inner bricks sweep
+        sweep(A, B, "inner")             # ... while the inner bricks sweep
         main.wait_event(ev1)
-        apply_stencil(stencil, A, B, brick_range=(sep0, sep2), coeff=coeff, stream=main)
+        sweep(A, B, "shell")
     for _ in range(S // 2 - 1):
-        apply_stencil(stencil, B, A, brick_range=(1, sep2), coeff=coeff, stream=main)
-        apply_stencil(stencil, A, B, brick_range=(1, sep2), coeff=coeff, stream=main)
-    apply_stencil(stencil, B, A, brick_range=(1, sep1), coeff=coeff, stream=main)
+        sweep(B, A, "all")
+        sweep(A, B, "all")
+    sweep(B, A, "domain")
     return S

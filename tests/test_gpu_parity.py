@@ -180,10 +180,12 @@ def test_weak_cycle_virtual_ranks(oracle, dev, name, nranks):
     table = LinkTable(links, dev)
     S = bl.stencil_iters(name)
     ncycles = 2
+    from bricklib_amd.drivers import SweepLists
+    lists = SweepLists(d, dev) if nranks != 2 else None      # both the list and the plain-range schedules
     for _ in range(ncycles):
         table.run()                     # every rank's exchange
         for r in range(nranks):
-            weak_cycle(name, d, bl.Brick(info, stA[r], 0), bl.Brick(info, stB[r], 0), lambda s: None)
+            weak_cycle(name, d, bl.Brick(info, stA[r], 0), bl.Brick(info, stB[r], 0), lambda s: None, lists=lists)
     torch.cuda.synchronize()
     # oracle: global periodic field, wrap-padded by 8 cells, S sweeps per cycle
     gext = tuple(g + 16 for g in gdims)
@@ -204,3 +206,42 @@ def test_weak_cycle_virtual_ranks(oracle, dev, name, nranks):
         bl.copyFromBrick(dom, (0,) * 3, (8,) * 3, got, gdev, bl.Brick(info, stA[r], 0))
         err = np.abs(got[8:-8, 8:-8, 8:-8].cpu().numpy() - want).max()
         assert err <= TOL, (r, err)
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("name", ["7pt", "mpi7pt"])
+def test_star7_kernel_variants(oracle, dev, name, variant):
+    """every 7-point kernel variant (generic / one brick per wave / persistent pipelines), list and range forms,
+    list lengths around the pipeline's corner cases (fewer entries than waves, odd/even trip counts)."""
+    from bricklib_amd._lib import lib
+    sid = bl.STENCILS[name]
+    coeff = oracle.coeffs(129, 1) if name == "7pt" else None
+    try:
+        assert lib.brk_set_variant(sid, variant) == 0
+        # list form on the single/ layout
+        grid, grid_dev, bInfo, arr, st, bIn, ids = single_setup(oracle, dev, 48, 1024)
+        hin = np.ascontiguousarray(st.dat.cpu().numpy().reshape(-1, 1024)[:, :512]).reshape(-1)
+        for n in (ids.size, 1, 7, 33, 100):
+            st.dat.view(-1, 1024)[:, 512:] = 0
+            sub = ids[:n]
+            bl.apply_stencil(name, bIn, bl.Brick(bInfo, st, 512), ids=grid_to_device(sub, dev), coeff=coeff)
+            want = np.zeros_like(hin)
+            oracle.brick_stencil(NAMES[name], bInfo.adj_host, hin, want, 512, ids=sub, coeff=coeff)
+            got = st.dat.cpu().numpy().reshape(-1, 1024)[:, 512:]
+            assert np.abs(got - want.reshape(-1, 512)).max() <= TOL, (n,)
+        # range form on the BrickDecomp layout (large enough that persistent waves take several trips)
+        dom = (160, 152, 168)
+        d = bl.BrickDecomp(dom)
+        info = d.getBrickInfo(dev)
+        A, B = info.allocate(512, dev), info.allocate(512, dev)
+        A.dat.uniform_(0.0, 1.0)
+        A.dat[:512] = 0
+        for rng_ in ((1, d.sep_pos[2]), (d.sep_pos[0], d.sep_pos[1]), (5, 6)):
+            B.dat.zero_()
+            bl.apply_stencil(name, bl.Brick(info, A, 0), bl.Brick(info, B, 0), brick_range=rng_, coeff=coeff)
+            hin2 = A.dat.cpu().numpy()
+            want = np.zeros_like(hin2)
+            oracle.brick_stencil(NAMES[name], d.adj, hin2, want, 512, n=rng_[1] - rng_[0], first=rng_[0], coeff=coeff)
+            assert np.abs(B.dat.cpu().numpy() - want).max() <= TOL, rng_
+    finally:
+        lib.brk_set_variant(sid, 0)

@@ -1,0 +1,290 @@
+// kbench -- native micro-benchmark of libbrk.so kernel variants (development tool, not part of the product).
+//   kbench [-n N] [-s stencil_id] [-v v1,v2,...] [-i iters] [-d] [-r]
+//     -d  BrickDecomp ordering + range API over [1,sep1) with two storages (weak/ shape); default is the
+//         single/ shape: lexicographic (N/8+2)^3 grid, interleaved storage (step 1024), list API over the interior
+//     -r  shuffle the brick list (worst-case locality)
+// Every variant is checked against variant 1 (generic kernel) with a device-side max|a-b|.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "brk.h"
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e = (x);                                                            \
+    if (e != hipSuccess) {                                                         \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));                       \
+      exit(2);                                                                     \
+    }                                                                              \
+  } while (0)
+#define BK(x)                                                      \
+  do {                                                             \
+    int rc = (x);                                                  \
+    if (rc) {                                                      \
+      fprintf(stderr, "%s -> %d: %s\n", #x, rc, brk_last_error()); \
+      exit(3);                                                     \
+    }                                                              \
+  } while (0)
+
+__global__ void k_fill(double *p, size_t n, unsigned long long seed) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long x = (i + seed) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 32;
+    p[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+  }
+}
+
+// max |a-b| over the out fields of the listed bricks
+__global__ void k_maxdiff(const double *a, const double *b, size_t step, const uint32_t *ids, uint32_t first, uint32_t n,
+                          unsigned long long *res) {
+  double m = 0;
+  for (size_t w = blockIdx.x; w < n; w += gridDim.x) {
+    uint32_t id = ids ? ids[w] : first + (uint32_t)w;
+    for (int e = threadIdx.x; e < 512; e += blockDim.x) {
+      double d = fabs(a[(size_t)id * step + e] - b[(size_t)id * step + e]);
+      if (!(d <= m)) m = d; // NaN propagates as "large"
+    }
+  }
+  if (m != m) m = 1e300;
+  atomicMax(res, (unsigned long long)__double_as_longlong(m));
+}
+
+// streaming ceilings with the same per-wave footprint as the stencil kernels (one 4 KiB brick per wave)
+__global__ __launch_bounds__(256) void k_stream2(const double *in, double *out, size_t step, const uint32_t *ids, uint32_t n) {
+  uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n) return;
+  uint32_t b = ids[w];
+  int lane = threadIdx.x & 63;
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = in[(size_t)b * step + k * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[(size_t)b * step + k * 64 + lane] = v[k] * 1.0001;
+}
+__global__ __launch_bounds__(256) void k_stream4(const double *in, double *out, size_t step, const uint32_t *ids, uint32_t n) {
+  uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n) return;
+  uint32_t b = ids[w];
+  int lane = threadIdx.x & 63;
+  const double2 *src = (const double2 *)(in + (size_t)b * step);
+  double2 *dst = (double2 *)(out + (size_t)b * step);
+  double2 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = src[k * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k].x *= 1.0001;
+    v[k].y *= 1.0001;
+    dst[k * 64 + lane] = v[k];
+  }
+}
+
+// linear float4 grid-stride copy (the guide's 6.29 TB/s reference shape)
+__global__ __launch_bounds__(256) void k_copy_lin(const uint4 *in, uint4 *out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+// one brick per wave, brick id = first + wave (no id list)
+__global__ __launch_bounds__(256) void k_stream2_range(const double *in, double *out, size_t step, uint32_t first, uint32_t n) {
+  uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n) return;
+  uint32_t b = first + w;
+  int lane = threadIdx.x & 63;
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = in[(size_t)b * step + k * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) out[(size_t)b * step + k * 64 + lane] = v[k] * 1.0001;
+}
+// persistent waves: each wave walks bricks w, w+W, ... with the next brick's loads in flight while storing
+__global__ __launch_bounds__(256) void k_stream2_persist(const double *in, double *out, size_t step, uint32_t first, uint32_t n) {
+  const uint32_t W = gridDim.x * 4;
+  uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  int lane = threadIdx.x & 63;
+  if (w >= n) return;
+  double a[8], b[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k] = in[(size_t)(first + w) * step + k * 64 + lane];
+  for (; w < n; w += 2 * W) {
+    uint32_t w1 = w + W < n ? w + W : w, w2 = w + 2 * W < n ? w + 2 * W : w;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) b[k] = in[(size_t)(first + w1) * step + k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[(size_t)(first + w) * step + k * 64 + lane] = a[k] * 1.0001;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = in[(size_t)(first + w2) * step + k * 64 + lane];
+    if (w + W < n) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) out[(size_t)(first + w1) * step + k * 64 + lane] = b[k] * 1.0001;
+    }
+  }
+}
+
+int main(int argc, char **argv) {
+  int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0;
+  bool decomp = false, shuffle = false, separate = false, stream = false;
+  std::vector<int> variants = {1, 2, 3, 4};
+  for (int a = 1; a < argc; ++a) {
+    std::string o = argv[a];
+    if (o == "-n") N = atoi(argv[++a]);
+    else if (o == "-s") sid = atoi(argv[++a]);
+    else if (o == "-i") iters = atoi(argv[++a]);
+    else if (o == "-d") decomp = true;
+    else if (o == "-r") shuffle = true;
+    else if (o == "-S") separate = true;   // lexicographic list but two storages (step 512)
+    else if (o == "-o") order = atoi(argv[++a]); // 0 lexi; J>0: per-XCD j-slabs of 8 rows, swept in sub-blocks of J rows over all k
+    else if (o == "-c") stream = true;     // also run the streaming-ceiling kernels
+    else if (o == "-v") {
+      variants.clear();
+      char *tok = strtok(argv[++a], ",");
+      while (tok) {
+        variants.push_back(atoi(tok));
+        tok = strtok(nullptr, ",");
+      }
+    }
+  }
+  std::vector<uint32_t> adj, ids;
+  uint32_t nbricks, first = 0, nlist;
+  size_t step;
+  if (decomp) {
+    brk_decomp *d;
+    uint32_t dims[3] = {(uint32_t)N, (uint32_t)N, (uint32_t)N};
+    BK(brk_decomp_build(dims, 8, &d));
+    nbricks = brk_decomp_nbricks(d);
+    adj.assign(brk_decomp_adj(d), brk_decomp_adj(d) + (size_t)nbricks * 27);
+    uint32_t sep[3];
+    brk_decomp_sep_pos(d, sep);
+    first = 1;
+    nlist = sep[1] - 1;
+    step = 512;
+    brk_decomp_free(d);
+  } else {
+    long SB = N / 8 + 2, dims[3] = {SB, SB, SB};
+    nbricks = (uint32_t)(SB * SB * SB);
+    std::vector<uint32_t> grid(nbricks);
+    adj.resize((size_t)nbricks * 27);
+    BK(brk_init_grid(dims, grid.data(), adj.data()));
+    const long NB = SB - 2;
+    if (order == 0) {
+      for (long k = 1; k < SB - 1; ++k)
+        for (long j = 1; j < SB - 1; ++j)
+          for (long i = 1; i < SB - 1; ++i) ids.push_back(grid[(k * SB + j) * SB + i]);
+    } else {
+      // XCD x gets rows [x*NB/8, (x+1)*NB/8); inside: blocks of `order` rows swept over all k (k-reuse distance =
+      // order*NB bricks), i fastest
+      const long rows = NB / 8;
+      for (long x = 0; x < 8; ++x)
+        for (long jb = 0; jb < rows; jb += order)
+          for (long k = 1; k < SB - 1; ++k)
+            for (long j = x * rows + jb; j < x * rows + jb + order && j < (x + 1) * rows; ++j)
+              for (long i = 1; i < SB - 1; ++i) ids.push_back(grid[(k * SB + (j + 1)) * SB + i]);
+    }
+    nlist = (uint32_t)ids.size();
+    step = separate ? 512 : 1024;
+  }
+  if (shuffle) {
+    if (ids.empty())
+      for (uint32_t q = 0; q < nlist; ++q) ids.push_back(first + q);
+    std::mt19937 g(7);
+    std::shuffle(ids.begin(), ids.end(), g);
+  }
+  const size_t elems = (size_t)nbricks * step;
+  double *st_in, *st_out, *st_ref;
+  uint32_t *adj_d, *ids_d = nullptr;
+  unsigned long long *res_d;
+  CK(hipMalloc(&st_in, elems * 8));
+  if (decomp || separate) {
+    CK(hipMalloc(&st_out, elems * 8));
+    CK(hipMalloc(&st_ref, elems * 8));
+  } else {
+    st_out = st_in + 512; // interleaved second field (stencils/3axis.cpp:25-28)
+    CK(hipMalloc(&st_ref, elems * 8));
+  }
+  CK(hipMalloc(&adj_d, adj.size() * 4));
+  CK(hipMalloc(&res_d, 8));
+  CK(hipMemcpy(adj_d, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
+  if (!ids.empty()) {
+    CK(hipMalloc(&ids_d, ids.size() * 4));
+    CK(hipMemcpy(ids_d, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+  }
+  k_fill<<<4096, 256>>>(st_in, elems, 1);
+  CK(hipMemset(st_ref, 0, elems * 8));
+  CK(hipDeviceSynchronize());
+  double coeff[129];
+  for (int i = 0; i < 129; ++i) coeff[i] = 0.01 * (i + 1);
+  const double *cp = (sid == BRK_7PT_COEFF || sid == BRK_27PT_COEFF) ? coeff : nullptr;
+  double *ref_out = (decomp || separate) ? st_ref : st_ref + 512;
+
+  auto launch = [&](double *out) {
+    if (ids_d)
+      BK(brk_stencil_apply_list(sid, adj_d, st_in, out, step, ids_d, nlist, cp, nullptr));
+    else
+      BK(brk_stencil_apply_range(sid, adj_d, st_in, out, step, first, first + nlist, cp, nullptr));
+  };
+  // reference output with the generic kernel
+  BK(brk_set_variant(sid, 1));
+  launch(ref_out);
+  CK(hipDeviceSynchronize());
+
+  printf("# N=%d stencil=%d bricks=%u list=%u %s%s order=%d step=%zu iters=%d\n", N, sid, nbricks, nlist,
+         decomp ? "decomp-range" : "lexi-list", shuffle ? " shuffled" : "", order, step, iters);
+  const double cells = (double)N * N * N;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  if (stream && ids_d) {
+    const char *names[] = {"stream2(ids)", "stream4(ids)", "copy_lin float4 2048 blocks", "copy_lin float4 8192 blocks",
+                           "stream2_range", "stream2_persist 2048 blocks", "stream2_persist 4096 blocks"};
+    for (int which = 0; which < 7; ++which) {
+      auto go = [&]() {
+        if (which == 0) k_stream2<<<(nlist + 3) / 4, 256>>>(st_in, st_out, step, ids_d, nlist);
+        else if (which == 1) k_stream4<<<(nlist + 3) / 4, 256>>>(st_in, st_out, step, ids_d, nlist);
+        else if (which == 2) k_copy_lin<<<2048, 256>>>((const uint4 *)st_in, (uint4 *)st_ref, (size_t)nlist * 512 / 2);
+        else if (which == 3) k_copy_lin<<<8192, 256>>>((const uint4 *)st_in, (uint4 *)st_ref, (size_t)nlist * 512 / 2);
+        else if (which == 4) k_stream2_range<<<(nlist + 3) / 4, 256>>>(st_in, st_out, step, 0, nlist);
+        else if (which == 5) k_stream2_persist<<<2048, 256>>>(st_in, st_out, step, 0, nlist);
+        else k_stream2_persist<<<4096, 256>>>(st_in, st_out, step, 0, nlist);
+      };
+      for (int w = 0; w < 3; ++w) go();
+      CK(hipEventRecord(e0));
+      for (int it = 0; it < iters; ++it) go();
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      printf("%-30s %.4f ms  %.0f GB/s (%.1f%% of 8 TB/s)\n", names[which], ms, 16.0 * cells / ms / 1e6,
+             16.0 * cells / ms / 1e6 / 80.0);
+    }
+  }
+  for (int round = 0; round < 2; ++round)
+    for (int v : variants) {
+      BK(brk_set_variant(sid, v));
+      for (int w = 0; w < 3; ++w) launch(st_out);
+      CK(hipEventRecord(e0));
+      for (int it = 0; it < iters; ++it) launch(st_out);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ms /= iters;
+      CK(hipMemset(res_d, 0, 8));
+      k_maxdiff<<<1024, 256>>>(st_out, ref_out, step, ids_d, first, nlist, res_d);
+      unsigned long long bits;
+      CK(hipMemcpy(&bits, res_d, 8, hipMemcpyDeviceToHost));
+      double md;
+      memcpy(&md, &bits, 8);
+      printf("variant %d  %.4f ms  %.1f GStencil/s  %.0f GB/s (%.1f%% of 8 TB/s)  maxdiff_vs_v1 %.3g\n", v, ms,
+             cells / ms / 1e6, 16.0 * cells / ms / 1e6, 16.0 * cells / ms / 1e6 / 80.0, md);
+      fflush(stdout);
+    }
+  return 0;
+}
