@@ -56,13 +56,29 @@ def verify_sample(bl, O, sid, info, st_in, st_out, step, off_out, ids, coeff, ns
     return float(np.abs(got - want.reshape(-1, 512)[sub]).max())
 
 
+def usable_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box exposes every
+    host thread in the mask but grants a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(O, sid, info, st, step, ids, coeff, n_cells, seconds):
-    """The oracle (CPU restatement, OpenMP over bricks) on the same sweep, all host cores, ~`seconds` of work."""
+    """The oracle (CPU restatement, OpenMP over bricks) on the same sweep, all usable host cores, ~`seconds` of work."""
+    cores = usable_cores()
+    O.L.orc_set_threads(cores)
     hin = st.dat.cpu().numpy().reshape(-1, step)
     fin = np.ascontiguousarray(hin[:, :512]).reshape(-1) if step != 512 else hin.reshape(-1)
     out = np.zeros_like(fin)
     ids = np.ascontiguousarray(ids, dtype=np.uint32)
-    O.brick_stencil(sid, info.adj_host, fin, out, 512, ids=ids, coeff=coeff)   # warm-up
+    for _ in range(2):
+        O.brick_stencil(sid, info.adj_host, fin, out, 512, ids=ids, coeff=coeff)   # warm-up (page faults, thread start)
     t0 = time.perf_counter()
     reps = 0
     while True:
@@ -71,7 +87,6 @@ def cpu_baseline(O, sid, info, st, step, ids, coeff, n_cells, seconds):
         dt = time.perf_counter() - t0
         if dt >= seconds:
             break
-    cores = len(os.sched_getaffinity(0))
     return {"value": n_cells * reps / dt / 1e9, "unit": "GStencil/s", "cores": cores, "kind": "port",
             "sample": f"{reps} full sweeps of the same {round(n_cells ** (1 / 3))}^3 brick list with oracle/brick_oracle.c "
                       f"(OpenMP, {cores} threads), {dt:.1f} s"}
@@ -116,7 +131,7 @@ def run_single(args, bl, dev):
     cells = float(N) ** 3
     res = {"workload": f"single-{name}-{N}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
-           "kernel": "k_star/k_cube<%s> over %d bricks" % (name, ids.size)}
+           "kernel": "%s over %d bricks" % ("k_s7_wg<8 waves>" if name in ("7pt", "mpi7pt") else ("k_star" if name in ("mpi13pt", "mpi25pt") else "k_cube"), ids.size)}
     extra = {}
     try:
         from oracle.oracle import Oracle
@@ -220,6 +235,15 @@ def main():
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],
                          "kernel_ms": res["kernel_ms"], "algorithmic_bytes_per_launch": res["alg_bytes_per_launch"]},
         }
+        # HBM-side traffic per launch from the committed PMC passes of this same command (prof_pmc.sh); null when the
+        # stored measurement is for another workload
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt.get("workload") == res["workload"]:
+                out["roofline"]["traffic"] = pt["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json"
+        except Exception:
+            pass
         out.update(extra)
         out.setdefault("cpu_baseline", None)
         print(json.dumps(out))

@@ -759,3 +759,13 @@ uint64_t orc_strong_getrank(uint64_t n, uint64_t zid, uint64_t subdim, uint64_t 
   }
   return zid;
 }
+
+/* thread control for the cpu_baseline leg of bench.py */
+#ifdef _OPENMP
+#include <omp.h>
+void orc_set_threads(int n) { omp_set_num_threads(n); }
+int orc_max_threads(void) { return omp_get_max_threads(); }
+#else
+void orc_set_threads(int n) { (void)n; }
+int orc_max_threads(void) { return 1; }
+#endif
