@@ -245,3 +245,55 @@ def test_star7_kernel_variants(oracle, dev, name, variant):
             assert np.abs(B.dat.cpu().numpy() - want).max() <= TOL, rng_
     finally:
         lib.brk_set_variant(sid, 0)
+
+
+@pytest.mark.parametrize("size", [1, 2, 3, 8])
+@pytest.mark.parametrize("name", ["mpi13pt", "mpi7pt"])
+def test_strong_cycle_virtual_ranks(oracle, dev, name, size):
+    """strong/main.cpp shape: 64^3 global domain, 16^3 subdomains in Z-Morton order over `size` ranks (all on one GPU;
+    per-peer pack -> loopback -> unpack as transport).  Oracle: the global periodic field swept on the CPU."""
+    from bricklib_amd.strong import StrongRank, loopback_transport
+    dom, sdom, seed = 64, 16, 21
+    ranks = [StrongRank(dom, sdom, r, size, dev) for r in range(size)]
+    assert sum(sr.nsub for sr in ranks) == (dom // sdom) ** 3
+    ext = (sdom + 16,) * 3
+    for sr in ranks:
+        for m in range(sr.nsub):
+            o = sr.origin(m)
+            arr = oracle.fill_array_global(ext, [x - 8 for x in o], (dom,) * 3, seed)
+            arr[:8], arr[-8:], arr[:, :8], arr[:, -8:], arr[:, :, :8], arr[:, :, -8:] = (-1e3,) * 6
+            bl.copyToBrick(ext, (0,) * 3, (0,) * 3, torch.from_numpy(arr).to(dev), sr.grid_dev, sr.sub_brick(0, m))
+    transport = loopback_transport(ranks)
+    S = bl.stencil_iters(name)
+    ncycles = 2
+    for _ in range(ncycles):
+        for sr in ranks:
+            sr.exchange_begin()
+        for sr in ranks:
+            if sr.peers:
+                transport(sr)
+        for sr in ranks:
+            sr.exchange_end()
+            sr.sweeps(name)
+    torch.cuda.synchronize()
+    if size > 1:
+        assert any(sr.bytes_remote > 0 for sr in ranks)
+    gext = (dom + 16,) * 3
+    cur = oracle.fill_array_global(gext, (-8,) * 3, (dom,) * 3, seed)
+    R = oracle.radius(NAMES[name])
+    for _ in range(ncycles):
+        for s_ in range(1, S + 1):
+            nxt = np.zeros_like(cur)
+            m_ = s_ * R
+            oracle.array_stencil(NAMES[name], cur, nxt, (m_,) * 3, tuple(g - m_ for g in gext))
+            cur = nxt
+        core = cur[8:-8, 8:-8, 8:-8].copy()
+        cur = np.pad(core, 8, mode="wrap")
+    for sr in ranks:
+        for m in range(sr.nsub):
+            o = sr.origin(m)
+            want = core[o[2]:o[2] + sdom, o[1]:o[1] + sdom, o[0]:o[0] + sdom]
+            got = torch.zeros(ext[::-1], dtype=torch.float64, device=dev)
+            bl.copyFromBrick((sdom,) * 3, (0,) * 3, (8,) * 3, got, sr.grid_dev, sr.sub_brick(0, m))
+            err = np.abs(got[8:-8, 8:-8, 8:-8].cpu().numpy() - want).max()
+            assert err <= TOL, (sr.rank, m, err)
