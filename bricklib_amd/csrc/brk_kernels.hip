@@ -28,194 +28,20 @@ __device__ __forceinline__ uint32_t wave_slot(uint32_t n) {
 }
 
 // ================================================================================================================
-// Star stencils (7-pt, 13-pt, 25-pt): centre + R points along each axis.
-// LDS per wave: TJ[8][8+2R][8] (j-extended planes, dense: conflict-free 64-B rows) and TI[8][8][PI]
-// (i-extended rows).  PI is chosen so that the four 8-double rows one 32-lane half touches fall on different
-// banks (ds_read_b64: 32 double-wide banks): 10 for R=1, 12 for R=2 (4 of 32 lanes 2-way), 24 for R=4.
+// Generic kernels: one wave per brick, 4 waves per workgroup; the per-brick bodies live in include/brick-device.h
+// (shared with user kernels that call brk::brick_apply from a rewritten brick(...) line).
 // ================================================================================================================
-template <int R>
-struct StarTile {
-  static constexpr int T = 8 + 2 * R;
-  static constexpr int PI = R == 1 ? 10 : (R == 2 ? 12 : 24);
-  static constexpr int TJ_ELEMS = 8 * T * 8;
-  static constexpr int TI_ELEMS = 8 * 8 * PI;
-  static constexpr int ELEMS = TJ_ELEMS + TI_ELEMS;
-  __device__ static constexpr int tj(int k, int jj, int i) { return (k * T + jj) * 8 + i; }
-  __device__ static constexpr int ti(int k, int j, int ii) { return TJ_ELEMS + (k * 8 + j) * PI + ii; }
-};
-
-enum StarKind { kStar7Coeff, kStarMpi7, kStarMpi13, kStarMpi25 };
-
-template <int KIND>
-struct StarTraits;
-template <> struct StarTraits<kStar7Coeff> { static constexpr int R = 1; };
-template <> struct StarTraits<kStarMpi7> { static constexpr int R = 1; };
-template <> struct StarTraits<kStarMpi13> { static constexpr int R = 2; };
-template <> struct StarTraits<kStarMpi25> { static constexpr int R = 4; };
-
 template <int KIND>
 __global__ __launch_bounds__(kWG) void k_star(const uint32_t *__restrict__ adj, const double *__restrict__ in,
                                                double *__restrict__ out, size_t step,
                                                const uint32_t *__restrict__ ids, uint32_t first, uint32_t n,
                                                Coeffs cf) {
-  constexpr int R = StarTraits<KIND>::R;
-  using TL = StarTile<R>;
-  __shared__ double lds[kWavesPerWG * TL::ELEMS];
-
+  __shared__ double lds[kWavesPerWG * StarTile<StarTraits<KIND>::R>::ELEMS];
   const uint32_t slot = wave_slot(n);
   if (slot >= n) return; // wave-uniform; no workgroup barrier anywhere below
-  const int lane = threadIdx.x & 63;
-  const int hi = lane >> 3, lo = lane & 7; // (j,i) when computing; (k,i) / (k,j) when staging faces
-  double *tile = lds + (threadIdx.x >> 6) * TL::ELEMS;
-
   const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
-  // one coalesced 108-B read of the adjacency row, then lane -> SGPR broadcasts
-  const uint32_t arow = adj[(size_t)b * 27 + (lane < 27 ? lane : 13)];
-  const uint32_t n_km = __builtin_amdgcn_readlane(arow, adj_slot(-1, 0, 0));
-  const uint32_t n_kp = __builtin_amdgcn_readlane(arow, adj_slot(1, 0, 0));
-  const uint32_t n_jm = __builtin_amdgcn_readlane(arow, adj_slot(0, -1, 0));
-  const uint32_t n_jp = __builtin_amdgcn_readlane(arow, adj_slot(0, 1, 0));
-  const uint32_t n_im = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, -1));
-  const uint32_t n_ip = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, 1));
-
-  const double *self = in + (size_t)b * step;
-  const double *p_km = in + (size_t)n_km * step, *p_kp = in + (size_t)n_kp * step;
-  const double *p_jm = in + (size_t)n_jm * step, *p_jp = in + (size_t)n_jp * step;
-  const double *p_im = in + (size_t)n_im * step, *p_ip = in + (size_t)n_ip * step;
-
-  // ---- issue every global load of this brick before touching LDS (all in flight together)
-  double col[8 + 2 * R]; // column (.., j, i) along k: [0,R) below, [R,R+8) own, [R+8,R+8+R) above
-#pragma unroll
-  for (int k = 0; k < 8; ++k) col[R + k] = self[k * 64 + lane];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    col[r] = p_km[(8 - R + r) * 64 + lane];
-    col[R + 8 + r] = p_kp[r * 64 + lane];
-  }
-  double fjm[R], fjp[R], fim[R], fip[R]; // faces: lane = (k=hi, i=lo) for j faces, (k=hi, j=lo) for i faces
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    fjm[r] = p_jm[hi * 64 + (8 - R + r) * 8 + lo];
-    fjp[r] = p_jp[hi * 64 + r * 8 + lo];
-    fim[r] = p_im[hi * 64 + lo * 8 + (8 - R + r)];
-    fip[r] = p_ip[hi * 64 + lo * 8 + r];
-  }
-
-  // ---- stage the in-plane neighbourhood
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    tile[TL::tj(k, hi + R, lo)] = col[R + k];
-    tile[TL::ti(k, hi, lo + R)] = col[R + k];
-  }
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    tile[TL::tj(hi, r, lo)] = fjm[r];
-    tile[TL::tj(hi, R + 8 + r, lo)] = fjp[r];
-    tile[TL::ti(hi, lo, r)] = fim[r];
-    tile[TL::ti(hi, lo, R + 8 + r)] = fip[r];
-  }
-  wave_lds_sync();
-
-  // ---- compute 8 planes; lane = (j=hi, i=lo)
-  double *dst = out + (size_t)b * step;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    double jm[R], jp[R], im[R], ip[R];
-#pragma unroll
-    for (int r = 1; r <= R; ++r) {
-      jm[r - 1] = tile[TL::tj(k, hi + R - r, lo)];
-      jp[r - 1] = tile[TL::tj(k, hi + R + r, lo)];
-      im[r - 1] = tile[TL::ti(k, hi, lo + R - r)];
-      ip[r - 1] = tile[TL::ti(k, hi, lo + R + r)];
-    }
-    const double c0 = col[R + k];
-    double res;
-    if (KIND == kStar7Coeff) {
-      // stencils/3axis.cpp:60-63 term order
-      res = cf.c[5] * col[R + k + 1] + cf.c[6] * col[R + k - 1] + cf.c[3] * jp[0] + cf.c[4] * jm[0] +
-            cf.c[1] * ip[0] + cf.c[2] * im[0] + cf.c[0] * c0;
-    } else if (KIND == kStarMpi7) {
-      // stencils/fake.h:346-349
-      res = (col[R + k + 1] + col[R + k - 1] + jp[0] + jm[0] + ip[0] + im[0]) * cf.c[1] + c0 * cf.c[0];
-    } else {
-      // stencils/fake.h:41-53 (25-pt) / :73-79 (13-pt): outermost shell first, centre last
-      res = 0.0;
-#pragma unroll
-      for (int r = R; r >= 1; --r) {
-        const double sh = col[R + k + r] + col[R + k - r] + jp[r - 1] + jm[r - 1] + ip[r - 1] + im[r - 1];
-        res = (r == R) ? sh * cf.c[r] : res + sh * cf.c[r];
-      }
-      res = res + c0 * cf.c[0];
-    }
-    dst[k * 64 + lane] = res;
-  }
-}
-
-// ================================================================================================================
-// Cube stencils (27-pt, 125-pt): full (8+2R)^3 tile in LDS.  Faces are staged with structured, coalesced
-// loads; the 20 edge/corner blocks through a precomputed per-lane descriptor table.  Compute runs in scatter
-// form: each tile value is read once per (dj,di) and FMA'd into the up-to-(2R+1) k-outputs it feeds.
-// ================================================================================================================
-template <int R>
-struct CubeTile {
-  static constexpr int T = 8 + 2 * R;
-  static constexpr int P = R == 1 ? 10 : 12; // i pitch in doubles (R=1 conflict-free; R=2 4 of 32 lanes 2-way)
-  static constexpr int ELEMS = T * T * P;
-  __host__ __device__ static constexpr int at(int kk, int jj, int ii) { return (kk * T + jj) * P + ii; }
-  static constexpr int NEXTRA = T * T * T - 512 - 6 * 64 * R;
-  static constexpr int EXTRA_ITERS = (NEXTRA + 63) / 64;
-};
-
-// descriptor = tile index | adjacency slot << 16 | element offset inside the source brick << 21
-template <int R>
-struct ExtraTable {
-  uint32_t e[CubeTile<R>::EXTRA_ITERS * 64];
-};
-
-template <int R>
-constexpr ExtraTable<R> make_extra_table() {
-  ExtraTable<R> t{};
-  constexpr int T = 8 + 2 * R;
-  int n = 0;
-  for (int kk = 0; kk < T; ++kk)
-    for (int jj = 0; jj < T; ++jj)
-      for (int ii = 0; ii < T; ++ii) {
-        const int dk = kk < R ? -1 : (kk >= R + 8 ? 1 : 0);
-        const int dj = jj < R ? -1 : (jj >= R + 8 ? 1 : 0);
-        const int di = ii < R ? -1 : (ii >= R + 8 ? 1 : 0);
-        if ((dk != 0) + (dj != 0) + (di != 0) < 2) continue;
-        const int sk = (kk - R + 8) % 8, sj = (jj - R + 8) % 8, si = (ii - R + 8) % 8;
-        t.e[n++] = (uint32_t)CubeTile<R>::at(kk, jj, ii) | ((uint32_t)adj_slot(dk, dj, di) << 16) |
-                   ((uint32_t)(sk * 64 + sj * 8 + si) << 21);
-      }
-  for (; n < CubeTile<R>::EXTRA_ITERS * 64; ++n) t.e[n] = 0xFFFFFFFFu;
-  return t;
-}
-
-__device__ const ExtraTable<1> g_extra1 = make_extra_table<1>();
-__device__ const ExtraTable<2> g_extra2 = make_extra_table<2>();
-
-template <int R>
-__device__ __forceinline__ const uint32_t *extra_table() {
-  if (R == 1) return g_extra1.e;
-  return g_extra2.e;
-}
-
-enum CubeKind { kCube27, kCube125 };
-template <int KIND> struct CubeTraits;
-template <> struct CubeTraits<kCube27> { static constexpr int R = 1; };
-template <> struct CubeTraits<kCube125> { static constexpr int R = 2; };
-
-// coefficient class of a 125-pt offset: sorted(|di|,|dj|,|dk|) -> 0..9 (stencils/mpi125pt.py:12-33)
-__host__ __device__ constexpr int cls125(int a, int b, int c) {
-  a = a < 0 ? -a : a;
-  b = b < 0 ? -b : b;
-  c = c < 0 ? -c : c;
-  const int lo = a < b ? (a < c ? a : c) : (b < c ? b : c);
-  const int hi = a > b ? (a > c ? a : c) : (b > c ? b : c);
-  const int mid = a + b + c - lo - hi;
-  // (lo,mid,hi): 000 001 002 011 012 022 111 112 122 222
-  return lo == 0 ? (mid == 0 ? hi : (mid == 1 ? 2 + hi : 5)) : (lo == 1 ? (mid == 1 ? 5 + hi : 8) : 9);
+  star_brick<KIND>(lds + (threadIdx.x >> 6) * StarTile<StarTraits<KIND>::R>::ELEMS, adj, in, out, step, b, cf,
+                   threadIdx.x & 63);
 }
 
 template <int KIND>
@@ -223,92 +49,12 @@ __global__ __launch_bounds__(kWG) void k_cube(const uint32_t *__restrict__ adj, 
                                                double *__restrict__ out, size_t step,
                                                const uint32_t *__restrict__ ids, uint32_t first, uint32_t n,
                                                Coeffs cf) {
-  constexpr int R = CubeTraits<KIND>::R;
-  using TL = CubeTile<R>;
-  __shared__ double lds[kWavesPerWG * TL::ELEMS];
-
+  __shared__ double lds[kWavesPerWG * CubeTile<CubeTraits<KIND>::R>::ELEMS];
   const uint32_t slot = wave_slot(n);
   if (slot >= n) return;
-  const int lane = threadIdx.x & 63;
-  const int hi = lane >> 3, lo = lane & 7;
-  double *tile = lds + (threadIdx.x >> 6) * TL::ELEMS;
-
   const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
-  const uint32_t arow = adj[(size_t)b * 27 + (lane < 27 ? lane : 13)];
-  const double *self = in + (size_t)b * step;
-  const double *p_km = in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(-1, 0, 0)) * step;
-  const double *p_kp = in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(1, 0, 0)) * step;
-  const double *p_jm = in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, -1, 0)) * step;
-  const double *p_jp = in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 1, 0)) * step;
-  const double *p_im = in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 0, -1)) * step;
-  const double *p_ip = in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 0, 1)) * step;
-
-  // ---- loads: own brick, 6 faces, then edge/corner cells via descriptors
-  double own[8], fkm[R], fkp[R], fjm[R], fjp[R], fim[R], fip[R];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) own[k] = self[k * 64 + lane];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    fkm[r] = p_km[(8 - R + r) * 64 + lane];
-    fkp[r] = p_kp[r * 64 + lane];
-    fjm[r] = p_jm[hi * 64 + (8 - R + r) * 8 + lo];
-    fjp[r] = p_jp[hi * 64 + r * 8 + lo];
-    fim[r] = p_im[hi * 64 + lo * 8 + (8 - R + r)];
-    fip[r] = p_ip[hi * 64 + lo * 8 + r];
-  }
-  const uint32_t *xt = extra_table<R>();
-  double xv[TL::EXTRA_ITERS];
-  uint32_t xd[TL::EXTRA_ITERS];
-#pragma unroll
-  for (int t = 0; t < TL::EXTRA_ITERS; ++t) {
-    xd[t] = xt[t * 64 + lane];
-    const bool live = xd[t] != 0xFFFFFFFFu;
-    // neighbour id of this lane's cell: pull lane (slot) of the adjacency-row register
-    const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((xd[t] >> 16) & 31u) << 2), (int)arow);
-    xv[t] = live ? in[(size_t)nb * step + (xd[t] >> 21)] : 0.0;
-  }
-
-  // ---- stage
-#pragma unroll
-  for (int k = 0; k < 8; ++k) tile[TL::at(k + R, hi + R, lo + R)] = own[k];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    tile[TL::at(r, hi + R, lo + R)] = fkm[r];
-    tile[TL::at(R + 8 + r, hi + R, lo + R)] = fkp[r];
-    tile[TL::at(hi + R, r, lo + R)] = fjm[r];
-    tile[TL::at(hi + R, R + 8 + r, lo + R)] = fjp[r];
-    tile[TL::at(hi + R, lo + R, r)] = fim[r];
-    tile[TL::at(hi + R, lo + R, R + 8 + r)] = fip[r];
-  }
-#pragma unroll
-  for (int t = 0; t < TL::EXTRA_ITERS; ++t)
-    if (xd[t] != 0xFFFFFFFFu) tile[xd[t] & 0xFFFFu] = xv[t];
-  wave_lds_sync();
-
-  // ---- scatter-form accumulate; lane = (j=hi, i=lo)
-  double acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
-#pragma unroll
-  for (int kk = 0; kk < TL::T; ++kk) {
-#pragma unroll
-    for (int dj = -R; dj <= R; ++dj)
-#pragma unroll
-      for (int di = -R; di <= R; ++di) {
-        const double v = tile[TL::at(kk, hi + R + dj, lo + R + di)];
-#pragma unroll
-        for (int dk = -R; dk <= R; ++dk) {
-          const int k = kk - R - dk; // output plane fed through tap dk
-          if (k >= 0 && k < 8) {
-            const double w = KIND == kCube27 ? cf.c[adj_slot(dk, dj, di)] : cf.c[cls125(dk, dj, di)];
-            acc[k] += w * v;
-          }
-        }
-      }
-  }
-  double *dst = out + (size_t)b * step;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) dst[k * 64 + lane] = acc[k];
+  cube_brick<KIND>(lds + (threadIdx.x >> 6) * CubeTile<CubeTraits<KIND>::R>::ELEMS, adj, in, out, step, b, cf,
+                   threadIdx.x & 63);
 }
 
 // ================================================================================================================

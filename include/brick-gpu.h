@@ -1,0 +1,67 @@
+// brick-gpu.h -- moving brick metadata and storage between host and device (reference include/brick-gpu.h:38-99).
+// Include brick-hip.h, not this file.  Sizes are size_t here (the reference's `unsigned size` overflows past 4 GiB).
+#ifndef BRICK_GPU_FUNCS_H
+#define BRICK_GPU_FUNCS_H
+
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+
+#include "brick.h"
+
+#define gpuCheck(x) _gpuCheck(x, #x, __FILE__, __LINE__)
+
+template <typename T>
+void _gpuCheck(T e, const char *func, const char *file, const int line) {
+  if (e != gpuSuccess) {
+    printf("\"%s\" at %d in %s\n\treturned %d\n-> %s\n", func, line, file, (int)e, gpuGetErrorString(e));
+    exit(EXIT_FAILURE);
+  }
+}
+
+// new BrickInfo whose adjacency list lives on the destination side
+template <unsigned dims>
+BrickInfo<dims> movBrickInfo(BrickInfo<dims> &bInfo, gpuMemcpyKind kind) {
+  assert(kind == gpuMemcpyHostToDevice || kind == gpuMemcpyDeviceToHost);
+  BrickInfo<dims> ret = bInfo;
+  const size_t size = (size_t)bInfo.nbricks * static_power<3, dims>::value * sizeof(unsigned);
+  if (kind == gpuMemcpyHostToDevice)
+    gpuCheck(gpuMalloc(&ret.adj, size));
+  else
+    ret.adj = (typename BrickInfo<dims>::adjlist)malloc(size);
+  gpuCheck(gpuMemcpy(ret.adj, bInfo.adj, size, kind));
+  return ret;
+}
+
+// same, and the BrickInfo struct itself is placed on the destination (kernels then follow bIn.bInfo->adj)
+template <unsigned dims>
+BrickInfo<dims> *movBrickInfoDeep(BrickInfo<dims> &bInfo, gpuMemcpyKind kind) {
+  BrickInfo<dims> temp = movBrickInfo(bInfo, kind);
+  BrickInfo<dims> *ret;
+  if (kind == gpuMemcpyHostToDevice)
+    gpuCheck(gpuMalloc(&ret, sizeof(BrickInfo<dims>)));
+  else
+    ret = (BrickInfo<dims> *)malloc(sizeof(BrickInfo<dims>));
+  gpuCheck(gpuMemcpy(ret, &temp, sizeof(BrickInfo<dims>), kind));
+  return ret;
+}
+
+// new BrickStorage on the destination side holding a copy of the data
+inline BrickStorage movBrickStorage(BrickStorage &bStorage, gpuMemcpyKind kind) {
+  assert(kind == gpuMemcpyHostToDevice || kind == gpuMemcpyDeviceToHost);
+  BrickStorage ret = bStorage;
+  const size_t size = bStorage.step * (size_t)bStorage.chunks * sizeof(bElem);
+  bElem *datptr;
+  if (kind == gpuMemcpyHostToDevice) {
+    gpuCheck(gpuMalloc(&datptr, size));
+    gpuCheck(gpuMemcpy(datptr, bStorage.dat.get(), size, kind));
+    ret.dat = std::shared_ptr<bElem>(datptr, [](bElem *p) { (void)gpuFree(p); });
+  } else {
+    datptr = (bElem *)malloc(size);
+    gpuCheck(gpuMemcpy(datptr, bStorage.dat.get(), size, kind));
+    ret.dat = std::shared_ptr<bElem>(datptr, [](bElem *p) { free(p); });
+  }
+  return ret;
+}
+
+#endif // BRICK_GPU_FUNCS_H
