@@ -171,6 +171,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   // 7-point sweeps: specialised kernels (brk_star7.hip) unless variant 1 (generic star kernel) is requested
   if ((id == BRK_7PT_COEFF || id == BRK_MPI7) && g_variant[id] != 1)
     return launch_star7(id, g_variant[id] == 0 ? kDefaultStar7Variant : g_variant[id], adj, in, out, step, ids, first, n, cf, st);
+  if ((id == BRK_MPI13 || id == BRK_MPI25) && g_variant[id] != 1) return launch_star_wg(id, adj, in, out, step, ids, first, n, cf, st);
   switch (id) {
   case BRK_7PT_COEFF: hipLaunchKernelGGL(k_star<kStar7Coeff>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_MPI7: hipLaunchKernelGGL(k_star<kStarMpi7>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;

@@ -206,6 +206,96 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
   }
 }
 
+// ---- variant 7/8: as variant 5, and each wave owns KS bricks stacked in k -----------------------------------------
+// List layout per workgroup: KS groups of 8 entries; group s+1 holds the +k neighbours of group s (checked at run
+// time; any other list is still computed correctly, the k-faces are then loaded).  The k-face between two stacked
+// bricks never leaves the register file, so k-face traffic drops by (KS-1)/KS; all loads of the KS bricks are issued
+// up front.  The tile is reused brick after brick with two workgroup barriers per brick.
+template <bool MPI, int KS>
+__global__ __launch_bounds__(512, 4) void k_s7_wgk(const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                                    double *__restrict__ out, size_t step,
+                                                    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n,
+                                                    Coeffs cf) {
+  constexpr int NW = 8;
+  __shared__ double lds[NW * kTile];
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 3, lo = lane & 7;
+  double *tile = lds + w * kTile;
+  auto id_of = [&](uint32_t sl) -> uint32_t { return ids ? ids[sl] : first + sl; };
+
+  Faces f[KS];
+  uint32_t b[KS];
+  bool active[KS], share_im[KS], share_ip[KS], chain[KS]; // chain[s]: brick s+1 is the +k neighbour of brick s
+  Nbr nb[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const uint32_t slot = (wg * KS + s) * NW + w;
+    active[s] = slot < n;
+    b[s] = 0;
+    share_im[s] = share_ip[s] = chain[s] = false;
+    if (active[s]) {
+      b[s] = __builtin_amdgcn_readfirstlane(id_of(slot));
+      nb[s] = load_nbr(adj, b[s]);
+      const uint32_t b_prev = w > 0 ? __builtin_amdgcn_readfirstlane(id_of(slot - 1)) : 0xFFFFFFFFu;
+      const uint32_t b_next = (w + 1 < NW && slot + 1 < n) ? __builtin_amdgcn_readfirstlane(id_of(slot + 1)) : 0xFFFFFFFFu;
+      share_im[s] = __builtin_amdgcn_readfirstlane(nb[s].im) == b_prev;
+      share_ip[s] = __builtin_amdgcn_readfirstlane(nb[s].ip) == b_next;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s + 1 < KS; ++s)
+    chain[s] = active[s] && active[s + 1] && __builtin_amdgcn_readfirstlane(nb[s].kp) == b[s + 1] &&
+               __builtin_amdgcn_readfirstlane(nb[s + 1].km) == b[s];
+  // ---- every global load of the KS bricks, up front
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (!active[s]) continue;
+    const gcptr self = scalar_base(in + (size_t)b[s] * step);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[s].own[k] = self[k * 64 + lane];
+    f[s].jm = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb[s].jm) * step)[hi * 64 + 7 * 8 + lo];
+    f[s].jp = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb[s].jp) * step)[hi * 64 + lo];
+    f[s].km = f[s].kp = f[s].im = f[s].ip = 0.0;
+    if (!(s > 0 && chain[s > 0 ? s - 1 : 0]))
+      f[s].km = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb[s].km) * step)[7 * 64 + lane];
+    if (!(s + 1 < KS && chain[s]))
+      f[s].kp = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb[s].kp) * step)[lane];
+    if (!share_im[s]) f[s].im = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb[s].im) * step)[hi * 64 + lo * 8 + 7];
+    if (!share_ip[s]) f[s].ip = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb[s].ip) * step)[hi * 64 + lo * 8];
+  }
+  const int o_jm = hi * 8 + lo, o_jp = (hi + 2) * 8 + lo;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    if (active[s]) stage(tile, f[s], lane);
+    __syncthreads(); // tiles of brick level s are staged; sibling tiles readable
+    if (active[s]) {
+      gptr dst = (gptr)(out + (size_t)b[s] * step);
+      asm volatile("" : "+s"(dst)); // see scalar_base()
+      const int o_im = lo > 0 ? (hi + 1) * 8 + lo - 1 : (share_im[s] ? -kTile + (hi + 1) * 8 + 7 : 80 + hi);
+      const int o_ip = lo < 7 ? (hi + 1) * 8 + lo + 1 : (share_ip[s] ? kTile + (hi + 1) * 8 : 88 + hi);
+      const bool up = s > 0 && chain[s > 0 ? s - 1 : 0], dn = s + 1 < KS && chain[s];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double jm = tile[k * kPlane + o_jm], jp = tile[k * kPlane + o_jp];
+        const double im = tile[k * kPlane + o_im], ip = tile[k * kPlane + o_ip];
+        const double c0 = f[s].own[k];
+        const double km = k == 0 ? (up ? f[s > 0 ? s - 1 : 0].own[7] : f[s].km) : f[s].own[k > 0 ? k - 1 : 0];
+        const double kp = k == 7 ? (dn ? f[s + 1 < KS ? s + 1 : s].own[0] : f[s].kp) : f[s].own[k < 7 ? k + 1 : 7];
+        double res;
+        if (MPI)
+          res = (kp + km + jp + jm + ip + im) * cf.c[1] + c0 * cf.c[0];
+        else
+          res = cf.c[5] * kp + cf.c[6] * km + cf.c[3] * jp + cf.c[4] * jm + cf.c[1] * ip + cf.c[2] * im + cf.c[0] * c0;
+        dst[k * 64 + lane] = res;
+      }
+    }
+    if (s + 1 < KS) __syncthreads(); // all reads of level s are done before level s+1 overwrites the tiles
+  }
+}
+
 // ---- variant 3: persistent waves, 3-deep pipeline ---------------------------------------------------------------
 // Grid = 8 * wgs_per_xcd blocks.  XCD x (= blockIdx & 7, round-robin dispatch) owns list entries
 // [x*chunk, (x+1)*chunk); its waves take entries lw, lw+W, lw+2W, ... (W = waves per XCD).  Entry indices past the
@@ -314,6 +404,14 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
       if (mpi) hipLaunchKernelGGL((k_s7_wg<true, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
       else hipLaunchKernelGGL((k_s7_wg<false, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
     }
+  } else if (variant == 7 || variant == 8) {
+    const uint32_t ks = variant == 7 ? 2 : 4;
+    const uint32_t per_wg = 8 * ks;
+    const uint32_t wgs = (((n + per_wg - 1) / per_wg + 7) / 8) * 8;
+#define BRK_LAUNCH_WGK(M, K) hipLaunchKernelGGL((k_s7_wgk<M, K>), dim3(wgs), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf)
+    if (variant == 7) { if (mpi) BRK_LAUNCH_WGK(true, 2); else BRK_LAUNCH_WGK(false, 2); }
+    else { if (mpi) BRK_LAUNCH_WGK(true, 4); else BRK_LAUNCH_WGK(false, 4); }
+#undef BRK_LAUNCH_WGK
   } else if (variant >= 16 && variant < 24) {
     const uint32_t wgs = (((n + kWavesPerWG - 1) / kWavesPerWG + 7) / 8) * 8;
 #define BRK_DIAG(S) case 16 + S: hipLaunchKernelGGL((k_s7<false, S>), dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf); break

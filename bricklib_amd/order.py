@@ -11,17 +11,24 @@ import numpy as np
 NXCD = 8
 
 
-def tiled(ids3, rows_per_block=8, nxcd=NXCD):
+def tiled(ids3, rows_per_block=8, nxcd=NXCD, kstack=1):
     """ids3: array [nk][nj][ni] of brick ids (any subset of a grid in logical order).  Returns a flat list:
-    for each XCD slab of j-rows: for each block of <= rows_per_block rows: for k: for j in block: for i."""
+    for each XCD slab of j-rows: for each block of <= rows_per_block rows: for k: for j in block: for i.
+    kstack > 1 (needs ni % 8 == 0 and nk % kstack == 0, else falls back to 1): inside a row, groups of 8 i-bricks are
+    followed by the same 8 bricks of the next kstack-1 k-levels -- the layout the k-stacked kernels keep in registers."""
     ids3 = np.asarray(ids3)
     nk, nj, ni = ids3.shape
+    if kstack > 1 and (ni % 8 or nk % kstack):
+        kstack = 1
     bounds = [(nj * x) // nxcd for x in range(nxcd + 1)]
     parts = []
     for x in range(nxcd):
         for j0 in range(bounds[x], bounds[x + 1], rows_per_block):
             j1 = min(j0 + rows_per_block, bounds[x + 1])
-            parts.append(np.ascontiguousarray(ids3[:, j0:j1, :]).reshape(-1))
+            blk = np.ascontiguousarray(ids3[:, j0:j1, :])
+            if kstack > 1:   # [kb][s][j][ib][w] -> [kb][j][ib][s][w]
+                blk = blk.reshape(nk // kstack, kstack, j1 - j0, ni // 8, 8).transpose(0, 2, 3, 1, 4)
+            parts.append(np.ascontiguousarray(blk).reshape(-1))
     return np.concatenate(parts).astype(np.uint32) if parts else np.zeros(0, dtype=np.uint32)
 
 

@@ -4,10 +4,5 @@ mkdir -p gpurun_out
 K=tools/kbench
 run() { echo "== kbench $*"; timeout -k 10 240 $K "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo killed; exit 1; fi; }
 {
-run -n 512 -s 0 -v 2,5,6,23
-run -n 512 -s 0 -S -v 2,5,6
-run -n 512 -s 0 -S -o 8 -v 2,5,6
-run -n 512 -s 0 -o 8 -v 2,5,6
-run -n 512 -s 0 -d -v 2,5,6
-run -n 512 -s 2 -d -v 2,5,6
+run -n 512 -s 4 -S -o 8 -v 1,0 -i 10
 } 2>&1 | tee gpurun_out/kbench.log

@@ -208,7 +208,7 @@ def test_weak_cycle_virtual_ranks(oracle, dev, name, nranks):
         assert err <= TOL, (r, err)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("name", ["7pt", "mpi7pt"])
 def test_star7_kernel_variants(oracle, dev, name, variant):
     """every 7-point kernel variant (generic / one brick per wave / persistent pipelines), list and range forms,
@@ -221,14 +221,29 @@ def test_star7_kernel_variants(oracle, dev, name, variant):
         # list form on the single/ layout
         grid, grid_dev, bInfo, arr, st, bIn, ids = single_setup(oracle, dev, 48, 1024)
         hin = np.ascontiguousarray(st.dat.cpu().numpy().reshape(-1, 1024)[:, :512]).reshape(-1)
-        for n in (ids.size, 1, 7, 33, 100):
+        from bricklib_amd.order import tiled
+        g3 = grid.reshape(8, 8, 8)[1:-1, 1:-1, 1:-1]
+        for n in (ids.size, 1, 7, 33, 100, -2, -3):
             st.dat.view(-1, 1024)[:, 512:] = 0
-            sub = ids[:n]
+            # n < 0: the k-stacked list layouts (6x6x6 interior has ni % 8 != 0 -> plain order; exercised again below)
+            sub = ids[:n] if n > 0 else tiled(g3, kstack=-n)
             bl.apply_stencil(name, bIn, bl.Brick(bInfo, st, 512), ids=grid_to_device(sub, dev), coeff=coeff)
             want = np.zeros_like(hin)
             oracle.brick_stencil(NAMES[name], bInfo.adj_host, hin, want, 512, ids=sub, coeff=coeff)
             got = st.dat.cpu().numpy().reshape(-1, 1024)[:, 512:]
             assert np.abs(got - want.reshape(-1, 512)).max() <= TOL, (n,)
+        # k-stacked list layout on a grid whose interior is 8 bricks wide (sharing + register-carried k-faces active)
+        g2, info2 = bl.init_grid((10, 6, 10), dev)
+        st2 = bl.BrickStorage.allocate(info2.nbricks, 1024, dev)
+        st2.dat.uniform_(0.0, 1.0)
+        hin3 = np.ascontiguousarray(st2.dat.cpu().numpy().reshape(-1, 1024)[:, :512]).reshape(-1)
+        for ks in (1, 2, 4):
+            lst = tiled(g2.reshape(10, 6, 10)[1:-1, 1:-1, 1:-1], kstack=ks)
+            st2.dat.view(-1, 1024)[:, 512:] = 0
+            bl.apply_stencil(name, bl.Brick(info2, st2, 0), bl.Brick(info2, st2, 512), ids=grid_to_device(lst, dev), coeff=coeff)
+            want = np.zeros_like(hin3)
+            oracle.brick_stencil(NAMES[name], info2.adj_host, hin3, want, 512, ids=lst, coeff=coeff)
+            assert np.abs(st2.dat.cpu().numpy().reshape(-1, 1024)[:, 512:] - want.reshape(-1, 512)).max() <= TOL, ks
         # range form on the BrickDecomp layout (large enough that persistent waves take several trips)
         dom = (160, 152, 168)
         d = bl.BrickDecomp(dom)

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_stream2_persist(const double *in, doubl
 }
 
 int main(int argc, char **argv) {
-  int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0;
+  int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1;
   bool decomp = false, shuffle = false, separate = false, stream = false;
   std::vector<int> variants = {1, 2, 3, 4};
   for (int a = 1; a < argc; ++a) {
@@ -141,6 +141,7 @@ int main(int argc, char **argv) {
     else if (o == "-r") shuffle = true;
     else if (o == "-S") separate = true;   // lexicographic list but two storages (step 512)
     else if (o == "-o") order = atoi(argv[++a]); // 0 lexi; J>0: per-XCD j-slabs of 8 rows, swept in sub-blocks of J rows over all k
+    else if (o == "-k") kstack = atoi(argv[++a]); // with -o: workgroup = 8 i-bricks x kstack k-levels
     else if (o == "-c") stream = true;     // also run the streaming-ceiling kernels
     else if (o == "-v") {
       variants.clear();
@@ -183,9 +184,11 @@ int main(int argc, char **argv) {
       const long rows = NB / 8;
       for (long x = 0; x < 8; ++x)
         for (long jb = 0; jb < rows; jb += order)
-          for (long k = 1; k < SB - 1; ++k)
+          for (long k = 1; k < SB - 1; k += kstack)
             for (long j = x * rows + jb; j < x * rows + jb + order && j < (x + 1) * rows; ++j)
-              for (long i = 1; i < SB - 1; ++i) ids.push_back(grid[(k * SB + (j + 1)) * SB + i]);
+              for (long ib = 1; ib < SB - 1; ib += 8)
+                for (long s2 = 0; s2 < kstack; ++s2)
+                  for (long i = ib; i < ib + 8; ++i) ids.push_back(grid[((k + s2) * SB + (j + 1)) * SB + i]);
     }
     nlist = (uint32_t)ids.size();
     step = separate ? 512 : 1024;
