@@ -161,7 +161,8 @@ struct CubeTile {
   static constexpr int EXTRA_ITERS = (NEXTRA + 63) / 64;
 };
 
-// descriptor = tile index | adjacency slot << 16 | element offset inside the source brick << 21
+// descriptor = tile index | adjacency slot << 16 | element offset inside the source brick << 21 |
+//              i-side tag << 30 (0: cell has di = 0, 1: di = -1, 2: di = +1; lets a kernel skip the cells a sibling provides)
 template <int R>
 struct ExtraTable {
   uint32_t e[CubeTile<R>::EXTRA_ITERS * 64];
@@ -181,7 +182,7 @@ constexpr ExtraTable<R> make_extra_table() {
         if ((dk != 0) + (dj != 0) + (di != 0) < 2) continue;
         const int sk = (kk - R + 8) % 8, sj = (jj - R + 8) % 8, si = (ii - R + 8) % 8;
         t.e[n++] = (uint32_t)CubeTile<R>::at(kk, jj, ii) | ((uint32_t)adj_slot(dk, dj, di) << 16) |
-                   ((uint32_t)(sk * 64 + sj * 8 + si) << 21);
+                   ((uint32_t)(sk * 64 + sj * 8 + si) << 21) | ((uint32_t)(di < 0 ? 1 : (di > 0 ? 2 : 0)) << 30);
       }
   for (; n < CubeTile<R>::EXTRA_ITERS * 64; ++n) t.e[n] = 0xFFFFFFFFu;
   return t;
@@ -251,7 +252,7 @@ __device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restr
     const bool live = xd[t] != 0xFFFFFFFFu;
     // neighbour id of this lane's cell: pull lane (slot) of the adjacency-row register
     const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((xd[t] >> 16) & 31u) << 2), (int)arow);
-    xv[t] = live ? in[(size_t)nb * step + (xd[t] >> 21)] : 0.0;
+    xv[t] = live ? in[(size_t)nb * step + ((xd[t] >> 21) & 511u)] : 0.0;
   }
 
   // ---- stage
