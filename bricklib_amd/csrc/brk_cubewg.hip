@@ -31,16 +31,15 @@ __global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : 2)) void k
   const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t slot = wg * NW + w;
-  const bool active = slot < n;
   const int lane = threadIdx.x & 63;
   const int hi = lane >> 3, lo = lane & 7;
   double *tile = lds + w * TL::ELEMS;
   auto id_of = [&](uint32_t sl) -> uint32_t { return ids ? ids[sl] : first + sl; };
 
-  uint32_t b = 0;
+  const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;
+  const bool active = b != BRK_LIST_SKIP;
   bool share_im = false, share_ip = false;
   if (active) {
-    b = __builtin_amdgcn_readfirstlane(id_of(slot));
     const uint32_t arow = adj[(size_t)b * 27 + (lane < 27 ? lane : 13)]; // lanes 0..26: the adjacency row
     const uint32_t n_im = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, -1));
     const uint32_t n_ip = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, 1));

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(kWG) void k_star(const uint32_t *__restrict__ adj, 
   const uint32_t slot = wave_slot(n);
   if (slot >= n) return; // wave-uniform; no workgroup barrier anywhere below
   const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
+  if (b == BRK_LIST_SKIP) return;
   star_brick<KIND>(lds + (threadIdx.x >> 6) * StarTile<StarTraits<KIND>::R>::ELEMS, adj, in, out, step, b, cf,
                    threadIdx.x & 63);
 }
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(kWG) void k_cube(const uint32_t *__restrict__ adj, 
   const uint32_t slot = wave_slot(n);
   if (slot >= n) return;
   const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
+  if (b == BRK_LIST_SKIP) return;
   cube_brick<KIND>(lds + (threadIdx.x >> 6) * CubeTile<CubeTraits<KIND>::R>::ELEMS, adj, in, out, step, b, cf,
                    threadIdx.x & 63);
 }

@@ -39,17 +39,16 @@ __global__ __launch_bounds__(64 * NW, (StarTraits<KIND>::R == 4 ? 3 : 4)) void k
   const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t slot = wg * NW + w;
-  const bool active = slot < n;
   const int lane = threadIdx.x & 63;
   const int hi = lane >> 3, lo = lane & 7;
   double *tile = lds + w * TL::TILE;
   auto id_of = [&](uint32_t sl) -> uint32_t { return ids ? ids[sl] : first + sl; };
 
   double col[8 + 2 * R];
-  uint32_t b = 0;
+  const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;
+  const bool active = b != BRK_LIST_SKIP;
   bool share_im = false, share_ip = false;
   if (active) {
-    b = __builtin_amdgcn_readfirstlane(id_of(slot));
     const uint32_t *row = adj + (size_t)b * 27;
     const uint32_t n_km = __builtin_amdgcn_readfirstlane(row[adj_slot(-1, 0, 0)]);
     const uint32_t n_kp = __builtin_amdgcn_readfirstlane(row[adj_slot(1, 0, 0)]);

@@ -11,25 +11,50 @@ import numpy as np
 NXCD = 8
 
 
-def tiled(ids3, rows_per_block=8, nxcd=NXCD, kstack=1):
-    """ids3: array [nk][nj][ni] of brick ids (any subset of a grid in logical order).  Returns a flat list:
-    for each XCD slab of j-rows: for each block of <= rows_per_block rows: for k: for j in block: for i.
-    kstack > 1 (needs ni % 8 == 0 and nk % kstack == 0, else falls back to 1): inside a row, groups of 8 i-bricks are
-    followed by the same 8 bricks of the next kstack-1 k-levels -- the layout the k-stacked kernels keep in registers."""
-    ids3 = np.asarray(ids3)
+LIST_SKIP = 0xFFFFFFFF   # BRK_LIST_SKIP of include/brk.h: list entries the kernels ignore
+
+
+def _pad(a, n):
+    return a if a.size == n else np.concatenate([a, np.full(n - a.size, LIST_SKIP, dtype=np.uint32)])
+
+
+def slabs(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True):
+    """Per-XCD pieces of the tiled order of `ids3` ([nk][nj][ni] brick ids): XCD x gets its own slab of j-rows, swept
+    in blocks of <= rows_per_block rows over all k, i fastest.  pad_rows: rows are padded with LIST_SKIP to a multiple
+    of 8 entries so that a workgroup (8 consecutive entries) never straddles two rows."""
+    ids3 = np.asarray(ids3).astype(np.uint32)
     nk, nj, ni = ids3.shape
-    if kstack > 1 and (ni % 8 or nk % kstack):
-        kstack = 1
+    if pad_rows and ni % 8:
+        ids3 = np.concatenate([ids3, np.full((nk, nj, 8 - ni % 8), LIST_SKIP, dtype=np.uint32)], axis=2)
     bounds = [(nj * x) // nxcd for x in range(nxcd + 1)]
-    parts = []
+    out = []
     for x in range(nxcd):
-        for j0 in range(bounds[x], bounds[x + 1], rows_per_block):
-            j1 = min(j0 + rows_per_block, bounds[x + 1])
-            blk = np.ascontiguousarray(ids3[:, j0:j1, :])
-            if kstack > 1:   # [kb][s][j][ib][w] -> [kb][j][ib][s][w]
-                blk = blk.reshape(nk // kstack, kstack, j1 - j0, ni // 8, 8).transpose(0, 2, 3, 1, 4)
-            parts.append(np.ascontiguousarray(blk).reshape(-1))
-    return np.concatenate(parts).astype(np.uint32) if parts else np.zeros(0, dtype=np.uint32)
+        parts = [np.ascontiguousarray(ids3[:, j0:min(j0 + rows_per_block, bounds[x + 1]), :]).reshape(-1)
+                 for j0 in range(bounds[x], bounds[x + 1], rows_per_block)]
+        out.append(np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32))
+    return out
+
+
+def assemble(*piece_lists, nxcd=NXCD):
+    """Concatenate per-XCD pieces (each argument: a list of nxcd arrays) into ONE list whose x-th eighth is exactly XCD
+    x's work: the kernels give XCD x the x-th eighth of the list, so the eighths are padded to equal length (a
+    multiple of 8 entries) with LIST_SKIP."""
+    per = [np.concatenate([pl[x] for pl in piece_lists]) for x in range(nxcd)]
+    n = max(p.size for p in per)
+    n = (n + 7) // 8 * 8
+    return np.concatenate([_pad(p, n) for p in per]).astype(np.uint32)
+
+
+def chunks(ids, nxcd=NXCD):
+    """split a flat id list into nxcd contiguous pieces, each a multiple of 8 entries where possible"""
+    ids = np.asarray(ids, dtype=np.uint32)
+    per = ((ids.size + nxcd - 1) // nxcd + 7) // 8 * 8
+    return [ids[x * per:(x + 1) * per] for x in range(nxcd)]
+
+
+def tiled(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True):
+    """Flat tiled list of `ids3` ([nk][nj][ni] brick ids), see slabs()/assemble()."""
+    return assemble(slabs(ids3, rows_per_block, nxcd, pad_rows), nxcd=nxcd)
 
 
 def decomp_lists(d, rows_per_block=8):
@@ -37,13 +62,13 @@ def decomp_lists(d, rows_per_block=8):
     inner   -- [1,sep0), tiled                       (never reads a ghost brick)
     shell   -- [sep0,sep2) surface + ghost, id order (thin regions)
     surface -- [sep0,sep1) id order
-    all / domain -- inner + shell / inner + surface."""
+    all / domain -- inner + shell / inner + surface, interleaved per XCD."""
     nb = [d.dims[a] // 8 - 2 * (d.depth // 8) for a in range(3)]   # inner extent in bricks (i,j,k)
     inner = 1 + np.arange(nb[0] * nb[1] * nb[2], dtype=np.int64).reshape(nb[2], nb[1], nb[0])
     assert inner.size == d.sep_pos[0] - 1
-    inner_t = tiled(inner, rows_per_block)
+    inner_s = slabs(inner, rows_per_block)
     shell = np.arange(d.sep_pos[0], d.sep_pos[2], dtype=np.uint32)
     surface = np.arange(d.sep_pos[0], d.sep_pos[1], dtype=np.uint32)
-    return {"inner": inner_t, "shell": shell, "surface": surface,
-            "all": np.concatenate([inner_t, shell]),        # [1,sep2): subdomain + ghost ring
-            "domain": np.concatenate([inner_t, surface])}   # [1,sep1): the subdomain itself
+    return {"inner": assemble(inner_s), "shell": shell, "surface": surface,
+            "all": assemble(inner_s, chunks(shell)),          # [1,sep2): subdomain + ghost ring
+            "domain": assemble(inner_s, chunks(surface))}     # [1,sep1): the subdomain itself

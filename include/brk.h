@@ -68,7 +68,10 @@ int brk_stencil_apply_range(int stencil_id, const uint32_t *adj_dev, const doubl
                             size_t step_elems, uint32_t brick_begin, uint32_t brick_end, const double *coeff_host,
                             brk_stream s);
 /* Same over an explicit list of brick ids, e.g. the reference's `grid` array or any slice of it
- * (stencils/3axis.hip.cpp:36-39 `b = grid[tk][tj][ti]`, strong/main.cu:85-99). */
+ * (stencils/3axis.hip.cpp:36-39 `b = grid[tk][tj][ti]`, strong/main.cu:85-99).  Entries equal to BRK_LIST_SKIP are
+ * ignored; hosts use them to pad rows so that every group of 8 consecutive entries is a run of i-neighbours (the kernels
+ * share i-faces inside such a group). */
+#define BRK_LIST_SKIP 0xFFFFFFFFu
 int brk_stencil_apply_list(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
                            size_t step_elems, const uint32_t *brick_ids_dev, uint32_t n, const double *coeff_host,
                            brk_stream s);

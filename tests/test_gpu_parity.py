@@ -208,7 +208,7 @@ def test_weak_cycle_virtual_ranks(oracle, dev, name, nranks):
         assert err <= TOL, (r, err)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6])
 @pytest.mark.parametrize("name", ["7pt", "mpi7pt"])
 def test_star7_kernel_variants(oracle, dev, name, variant):
     """every 7-point kernel variant (generic / one brick per wave / persistent pipelines), list and range forms,
@@ -221,29 +221,19 @@ def test_star7_kernel_variants(oracle, dev, name, variant):
         # list form on the single/ layout
         grid, grid_dev, bInfo, arr, st, bIn, ids = single_setup(oracle, dev, 48, 1024)
         hin = np.ascontiguousarray(st.dat.cpu().numpy().reshape(-1, 1024)[:, :512]).reshape(-1)
-        from bricklib_amd.order import tiled
+        from bricklib_amd.order import LIST_SKIP, tiled
         g3 = grid.reshape(8, 8, 8)[1:-1, 1:-1, 1:-1]
-        for n in (ids.size, 1, 7, 33, 100, -2, -3):
+        for n in (ids.size, 1, 7, 33, 100, -1):
             st.dat.view(-1, 1024)[:, 512:] = 0
-            # n < 0: the k-stacked list layouts (6x6x6 interior has ni % 8 != 0 -> plain order; exercised again below)
-            sub = ids[:n] if n > 0 else tiled(g3, kstack=-n)
+            # n < 0: tiled order of the 6x6x6 interior: rows of 6 padded to 8 with BRK_LIST_SKIP entries
+            sub = ids[:n] if n > 0 else tiled(g3)
+            if n < 0:
+                assert sorted(sub[sub != LIST_SKIP].tolist()) == sorted(ids.tolist()) and (sub == LIST_SKIP).sum() >= 2 * 36
             bl.apply_stencil(name, bIn, bl.Brick(bInfo, st, 512), ids=grid_to_device(sub, dev), coeff=coeff)
             want = np.zeros_like(hin)
-            oracle.brick_stencil(NAMES[name], bInfo.adj_host, hin, want, 512, ids=sub, coeff=coeff)
+            oracle.brick_stencil(NAMES[name], bInfo.adj_host, hin, want, 512, ids=sub[sub != LIST_SKIP], coeff=coeff)
             got = st.dat.cpu().numpy().reshape(-1, 1024)[:, 512:]
             assert np.abs(got - want.reshape(-1, 512)).max() <= TOL, (n,)
-        # k-stacked list layout on a grid whose interior is 8 bricks wide (sharing + register-carried k-faces active)
-        g2, info2 = bl.init_grid((10, 6, 10), dev)
-        st2 = bl.BrickStorage.allocate(info2.nbricks, 1024, dev)
-        st2.dat.uniform_(0.0, 1.0)
-        hin3 = np.ascontiguousarray(st2.dat.cpu().numpy().reshape(-1, 1024)[:, :512]).reshape(-1)
-        for ks in (1, 2, 4):
-            lst = tiled(g2.reshape(10, 6, 10)[1:-1, 1:-1, 1:-1], kstack=ks)
-            st2.dat.view(-1, 1024)[:, 512:] = 0
-            bl.apply_stencil(name, bl.Brick(info2, st2, 0), bl.Brick(info2, st2, 512), ids=grid_to_device(lst, dev), coeff=coeff)
-            want = np.zeros_like(hin3)
-            oracle.brick_stencil(NAMES[name], info2.adj_host, hin3, want, 512, ids=lst, coeff=coeff)
-            assert np.abs(st2.dat.cpu().numpy().reshape(-1, 1024)[:, 512:] - want.reshape(-1, 512)).max() <= TOL, ks
         # range form on the BrickDecomp layout (large enough that persistent waves take several trips)
         dom = (160, 152, 168)
         d = bl.BrickDecomp(dom)
@@ -312,3 +302,65 @@ def test_strong_cycle_virtual_ranks(oracle, dev, name, size):
             bl.copyFromBrick((sdom,) * 3, (0,) * 3, (8,) * 3, got, sr.grid_dev, sr.sub_brick(0, m))
             err = np.abs(got[8:-8, 8:-8, 8:-8].cpu().numpy() - want).max()
             assert err <= TOL, (sr.rank, m, err)
+
+
+@pytest.mark.parametrize("name", list(NAMES))
+def test_padded_tiled_lists_all_stencils(oracle, dev, name):
+    """tiled order with BRK_LIST_SKIP padding (rows of 5 bricks) through every default kernel."""
+    from bricklib_amd.order import LIST_SKIP, tiled
+    grid, info = bl.init_grid((7, 9, 6), dev)
+    st = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    st.dat.uniform_(0.0, 1.0)
+    so = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    lst = tiled(grid.reshape(6, 9, 7)[1:-1, 1:-1, 1:-1])
+    assert (lst == LIST_SKIP).any()
+    coeff = oracle.coeffs(129, 1) if name in ("7pt", "27pt") else None
+    bl.apply_stencil(name, bl.Brick(info, st, 0), bl.Brick(info, so, 0), ids=grid_to_device(lst, dev), coeff=coeff)
+    hin = st.dat.cpu().numpy()
+    want = np.zeros_like(hin)
+    oracle.brick_stencil(NAMES[name], info.adj_host, hin, want, 512, ids=lst[lst != LIST_SKIP], coeff=coeff)
+    assert np.abs(so.dat.cpu().numpy() - want).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["7pt", "mpi13pt", "27pt"])
+def test_full_size_512_properties(oracle, dev, name):
+    """BASELINE size (512^3, 262144 bricks): size-independent properties + a sampled comparison with the oracle.
+      * linearity  S(a*x + b*y) == a*S(x) + b*S(y)
+      * a constant field maps to (sum of weights) * constant
+      * 1024 random bricks agree with the CPU oracle."""
+    from bricklib_amd.order import tiled
+    N, SB = 512, 66
+    grid, info = bl.init_grid((SB, SB, SB), dev)
+    ids = tiled(grid.reshape(SB, SB, SB)[1:-1, 1:-1, 1:-1])
+    ids_dev = grid_to_device(ids, dev)
+    coeff = oracle.coeffs(129, 1) if name in ("7pt", "27pt") else None
+    x, y, sx, sy, sz = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(5))
+    x.dat.uniform_(0.0, 1.0)
+    y.dat.uniform_(0.0, 1.0)
+    B = lambda s: bl.Brick(info, s, 0)
+    bl.apply_stencil(name, B(x), B(sx), ids=ids_dev, coeff=coeff)
+    bl.apply_stencil(name, B(y), B(sy), ids=ids_dev, coeff=coeff)
+    a, b = 0.75, -1.25
+    z = bl.BrickStorage(a * x.dat + b * y.dat, info.nbricks, 512)
+    bl.apply_stencil(name, B(z), B(sz), ids=ids_dev, coeff=coeff)
+    lin = (sz.dat - (a * sx.dat + b * sy.dat)).abs().max().item()
+    assert lin <= 1e-12, lin
+    # constant field
+    z.dat.fill_(2.5)
+    bl.apply_stencil(name, B(z), B(sz), ids=ids_dev, coeff=coeff)
+    if name == "7pt":
+        wsum = coeff[:7].sum()
+    elif name == "27pt":
+        wsum = coeff[:27].sum()      # the quirk moves coeff[16] to another tap, the sum is unchanged
+    else:
+        wsum = 0.4 + 6 * 0.07 + 6 * 0.03
+    inner = sz.dat.view(-1, 512)[torch.from_numpy(ids.astype(np.int64)).to(dev)]
+    assert (inner - 2.5 * wsum).abs().max().item() <= 1e-12
+    # sampled bricks vs oracle
+    rng = np.random.default_rng(3)
+    sub = np.sort(rng.choice(ids, 1024, replace=False)).astype(np.uint32)
+    hin = x.dat.cpu().numpy()
+    want = np.zeros_like(hin)
+    oracle.brick_stencil(NAMES[name], info.adj_host, hin, want, 512, ids=sub, coeff=coeff)
+    got = sx.dat.cpu().numpy().reshape(-1, 512)[sub]
+    assert np.abs(got - want.reshape(-1, 512)[sub]).max() <= TOL
