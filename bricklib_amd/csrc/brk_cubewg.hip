@@ -119,6 +119,11 @@ __global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : 2)) void k
     const int c = lo + di;
     col[di + R] = (c < 0 && share_im) ? -TL::ELEMS + R + c + 8 : ((c > 7 && share_ip) ? TL::ELEMS + R + c - 8 : R + c);
   }
+  if (KIND == kCube125) {
+    const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
+    cube125_accumulate<TL::T * TL::P, TL::P>(tile + (hi + R) * TL::P, co, cf, (double *)dst, lane);
+    return;
+  }
   double acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.0;

@@ -45,13 +45,17 @@ __global__ __launch_bounds__(kWG) void k_star(const uint32_t *__restrict__ adj, 
                    threadIdx.x & 63);
 }
 
-template <int KIND>
-__global__ __launch_bounds__(kWG) void k_cube(const uint32_t *__restrict__ adj, const double *__restrict__ in,
-                                               double *__restrict__ out, size_t step,
-                                               const uint32_t *__restrict__ ids, uint32_t first, uint32_t n,
-                                               Coeffs cf) {
-  __shared__ double lds[kWavesPerWG * CubeTile<CubeTraits<KIND>::R>::ELEMS];
-  const uint32_t slot = wave_slot(n);
+// WPW waves per workgroup: the 125-point tile is 13.5 KiB per wave, so 4-wave workgroups fit only twice per CU (8 waves);
+// single-wave workgroups reach 11 waves/CU.
+template <int KIND, int WPW>
+__global__ __launch_bounds__(64 * WPW) void k_cube(const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                                    double *__restrict__ out, size_t step,
+                                                    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n,
+                                                    Coeffs cf) {
+  __shared__ double lds[WPW * CubeTile<CubeTraits<KIND>::R>::ELEMS];
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t slot = wg * WPW + (threadIdx.x >> 6);
   if (slot >= n) return;
   const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
   if (b == BRK_LIST_SKIP) return;
@@ -184,8 +188,13 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   case BRK_MPI7: hipLaunchKernelGGL(k_star<kStarMpi7>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_MPI13: hipLaunchKernelGGL(k_star<kStarMpi13>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_MPI25: hipLaunchKernelGGL(k_star<kStarMpi25>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
-  case BRK_27PT_COEFF: hipLaunchKernelGGL(k_cube<kCube27>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
-  case BRK_MPI125: hipLaunchKernelGGL(k_cube<kCube125>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
+  case BRK_27PT_COEFF: hipLaunchKernelGGL((k_cube<kCube27, 4>), grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
+  case BRK_MPI125:
+    if (g_variant[id] == 3)
+      hipLaunchKernelGGL((k_cube<kCube125, 4>), grid, block, 0, st, adj, in, out, step, ids, first, n, cf);
+    else
+      hipLaunchKernelGGL((k_cube<kCube125, 1>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, cf);
+    break;
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;

@@ -214,6 +214,52 @@ __host__ __device__ constexpr int cls125(int a, int b, int c) {
   return lo == 0 ? (mid == 0 ? hi : (mid == 1 ? 2 + hi : 5)) : (lo == 1 ? (mid == 1 ? 5 + hi : 8) : 9);
 }
 
+// 125-point accumulation with mirror-image taps folded (the weights depend only on the sorted |offsets|, 10 classes,
+// stencils/mpi125pt.py:12-33): per tile plane, add the +-di pairs (2 adds per row, 5 rows), then the +-dj pairs (6 adds);
+// the 9 values u[a][b] (a = |di|, b = |dj|) feed the <=5 outputs k = kk-2-dk with weight C[class(|dk|,b,a)].
+// ~730 fp64 VALU ops per lane per brick instead of 1000 FMAs; LDS reads unchanged (300).
+// The plane loop is a real loop over a 5-entry ring of partial outputs: fully unrolled, hipcc hoists the LDS reads of all 12
+// planes (256 VGPRs + 256 AGPRs + scratch).  rowp: per-lane pointer to tile(plane 0, row j+R, column 0);
+// co[d]: per-lane column offset of tap di = d-2 (own tile, or a sibling's tile 8 columns away); PS/RS: plane/row pitch.
+template <int PS, int RS>
+__device__ __forceinline__ void cube125_accumulate(const double *rowp, const int (&co)[5], const Coeffs &cf,
+                                                   double *dst, int lane) {
+  double ring[5] = {0.0, 0.0, 0.0, 0.0, 0.0}; // ring[m] = partial output k = kk-4+m
+#pragma unroll 1
+  for (int kk = 0; kk < 12; ++kk, rowp += PS) {
+    double u[3][3];
+#pragma unroll
+    for (int dj = -2; dj <= 2; ++dj) {
+      const double *r = rowp + dj * RS;
+      const double s0 = r[co[2]], s1 = r[co[1]] + r[co[3]], s2 = r[co[0]] + r[co[4]];
+      const int bcls = dj < 0 ? -dj : dj;
+      if (dj <= 0) { // first visit of this |dj| class
+        u[0][bcls] = s0;
+        u[1][bcls] = s1;
+        u[2][bcls] = s2;
+      } else {
+        u[0][bcls] += s0;
+        u[1][bcls] += s1;
+        u[2][bcls] += s2;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      if ((unsigned)(kk - 4 + m) < 8u) { // wave-uniform: the output exists
+        const int c = m < 2 ? 2 - m : m - 2; // |dk|
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) ring[m] += cf.c[cls125(c, bb, a)] * u[a][bb];
+      }
+    }
+    if (kk >= 4) dst[(kk - 4) * 64 + lane] = ring[0]; // output kk-4 has received its last plane
+#pragma unroll
+    for (int m = 0; m < 4; ++m) ring[m] = ring[m + 1];
+    ring[4] = 0.0;
+  }
+}
+
 // One wave computes brick `b` (wave-uniform).  `tile` = this wave's private LDS slice of CubeTile<R>::ELEMS doubles.
 template <int KIND>
 __device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in,
@@ -276,22 +322,25 @@ __device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restr
   double acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+  if (KIND == kCube125) {
+    const int co[5] = {lo + R - 2, lo + R - 1, lo + R, lo + R + 1, lo + R + 2};
+    cube125_accumulate<TL::T * TL::P, TL::P>(tile + (hi + R) * TL::P, co, cf, out + (size_t)b * step, lane);
+    return;
+  } else {
 #pragma unroll
-  for (int kk = 0; kk < TL::T; ++kk) {
+    for (int kk = 0; kk < TL::T; ++kk) {
 #pragma unroll
-    for (int dj = -R; dj <= R; ++dj)
+      for (int dj = -R; dj <= R; ++dj)
 #pragma unroll
-      for (int di = -R; di <= R; ++di) {
-        const double v = tile[TL::at(kk, hi + R + dj, lo + R + di)];
+        for (int di = -R; di <= R; ++di) {
+          const double v = tile[TL::at(kk, hi + R + dj, lo + R + di)];
 #pragma unroll
-        for (int dk = -R; dk <= R; ++dk) {
-          const int k = kk - R - dk; // output plane fed through tap dk
-          if (k >= 0 && k < 8) {
-            const double w = KIND == kCube27 ? cf.c[adj_slot(dk, dj, di)] : cf.c[cls125(dk, dj, di)];
-            acc[k] += w * v;
+          for (int dk = -R; dk <= R; ++dk) {
+            const int k = kk - R - dk; // output plane fed through tap dk
+            if (k >= 0 && k < 8) acc[k] += cf.c[adj_slot(dk, dj, di)] * v;
           }
         }
-      }
+    }
   }
   double *dst = out + (size_t)b * step;
 #pragma unroll
