@@ -242,6 +242,29 @@ extern "C" int brk_stencil_apply_list(int id, const uint32_t *adj, const double 
   return launch_stencil(id, adj, in, out, step, ids, 0, n, coeff_host, s);
 }
 
+extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *in, double *out, size_t step,
+                                     uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3],
+                                     const double *coeff_host, brk_stream s) {
+  if (!tot || !lo || !cnt) return brk_fail(BRK_EINVAL, "null box geometry");
+  for (int a = 0; a < 3; ++a)
+    if (lo[a] + cnt[a] > tot[a]) return brk_fail(BRK_EINVAL, "box exceeds the grid on axis %d", a);
+  if ((uint64_t)base + (uint64_t)tot[0] * tot[1] * tot[2] > 0xFFFFFFFFull) return brk_fail(BRK_EINVAL, "brick ids overflow 32 bits");
+  if (!adj || !in || !out || in == out || step < 512) return brk_fail(BRK_EINVAL, "bad device pointers / step");
+  if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
+  if ((uint64_t)cnt[0] * cnt[1] * cnt[2] == 0) return BRK_OK;
+  Coeffs cf;
+  if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
+  if (id == BRK_7PT_COEFF || id == BRK_MPI7)
+    return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s));
+  // other stencils: no arithmetic walk yet -- sweep the box row by row through the range form (rows are contiguous ids)
+  for (uint32_t k = 0; k < cnt[2]; ++k)
+    for (uint32_t j = 0; j < cnt[1]; ++j) {
+      const uint32_t b0 = base + ((lo[2] + k) * tot[1] + (lo[1] + j)) * tot[0] + lo[0];
+      if (int rc = launch_stencil(id, adj, in, out, step, nullptr, b0, cnt[0], coeff_host, s)) return rc;
+    }
+  return BRK_OK;
+}
+
 extern "C" int brk_link_copy(const brk_link *links, uint32_t n, uint64_t max_bytes, brk_stream s) {
   if (n == 0 || max_bytes == 0) return BRK_OK;
   if (!links) return brk_fail(BRK_EINVAL, "null link table");

@@ -138,12 +138,49 @@ __global__ __launch_bounds__(kWG, 6) void k_s7(const uint32_t *__restrict__ adj,
 // ceiling.  When consecutive list entries are i-neighbours (the usual lexicographic order), the neighbour's data is
 // already staged in the sibling wave's tile: the i-edge lanes just point their ds_read into that tile (same bank as
 // the lane's own row -> still conflict-free).  Entries that are not i-neighbours fall back to the gather.
-template <bool MPI, int NW>
+// Brick ids of a structured box inside a lexicographic numbering: id = base + (k*nj_tot + j)*ni_tot + i for
+// (i,j,k) in [lo, lo+cnt).  The kernel walks the box in the order of bricklib_amd/order.py (one slab of j-rows per XCD,
+// blocks of 8 rows swept over all k, i fastest) computed arithmetically, so no id list is read at all.
+struct Box {
+  uint32_t base, ni_tot, nj_tot;
+  uint32_t lo[3], cnt[3];
+};
+
+enum { kModeRange = 0, kModeList = 1, kModeBox = 2 };
+
+// (brick id, previous, next, active) of wave w of workgroup `g` of XCD `x` in box mode
+__device__ __forceinline__ bool box_entry(const Box &bx, uint32_t x, uint32_t g, uint32_t w, uint32_t &b, bool &has_prev,
+                                          bool &has_next) {
+  const uint32_t G = (bx.cnt[0] + 7) / 8, nk = bx.cnt[2];
+  const uint32_t j_lo = (bx.cnt[1] * x) / 8, j_hi = (bx.cnt[1] * (x + 1)) / 8;
+  const uint32_t rows_x = j_hi - j_lo, full = rows_x / 8, rem = rows_x % 8;
+  const uint32_t per_full = nk * 8 * G;
+  uint32_t blk, r, rows;
+  if (g < full * per_full) {
+    blk = g / per_full;
+    r = g % per_full;
+    rows = 8;
+  } else {
+    blk = full;
+    r = g - full * per_full;
+    rows = rem;
+    if (rows == 0 || r >= nk * rows * G) return false;
+  }
+  const uint32_t k = r / (rows * G), r2 = r % (rows * G), j = r2 / G, ig = r2 % G;
+  const uint32_t i = ig * 8 + w;
+  if (i >= bx.cnt[0]) return false;
+  b = bx.base + ((bx.lo[2] + k) * bx.nj_tot + (bx.lo[1] + j_lo + blk * 8 + j)) * bx.ni_tot + bx.lo[0] + i;
+  has_prev = w > 0;
+  has_next = w + 1 < 8 && i + 1 < bx.cnt[0];
+  return true;
+}
+
+template <bool MPI, int NW, int MODE>
 __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uint32_t *__restrict__ adj,
                                                                       const double *__restrict__ in,
                                                                       double *__restrict__ out, size_t step,
                                                                       const uint32_t *__restrict__ ids, uint32_t first,
-                                                                      uint32_t n, Coeffs cf) {
+                                                                      uint32_t n, Box bx, Coeffs cf) {
   __shared__ double lds[NW * kTile];
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -152,25 +189,47 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
   const int lane = threadIdx.x & 63;
   const int hi = lane >> 3, lo = lane & 7;
   double *tile = lds + w * kTile;
-  auto id_of = [&](uint32_t sl) -> uint32_t { return ids ? ids[sl] : first + sl; };
+  // A wave's life is mostly latency (it moves 8 KiB and waits), so the dependent chain in front of the first vector
+  // load is kept short: the brick id and its two list neighbours come from three clamped scalar loads issued together
+  // (no branches), the adjacency row is requested next, and the 8 loads of the brick itself -- which need only the id --
+  // are issued before the adjacency row is waited for.
+  uint32_t b = 0, b_prev, b_next;
+  bool active, has_prev = w > 0, has_next = w + 1 < NW && slot + 1 < n;
+  if (MODE == kModeBox) {
+    static_assert(MODE != kModeBox || NW == 8, "box mode walks rows in groups of 8");
+    active = box_entry(bx, blockIdx.x & 7u, blockIdx.x >> 3, w, b, has_prev, has_next);
+    b = __builtin_amdgcn_readfirstlane(b);
+    b_prev = b - 1;
+    b_next = b + 1;
+  } else {
+    const uint32_t sl = slot < n ? slot : n - 1;
+    const uint32_t sp = sl > 0 ? sl - 1 : 0, sn = sl + 1 < n ? sl + 1 : n - 1;
+    if (MODE == kModeList) {
+      b = __builtin_amdgcn_readfirstlane(ids[sl]);
+      b_prev = __builtin_amdgcn_readfirstlane(ids[sp]);
+      b_next = __builtin_amdgcn_readfirstlane(ids[sn]);
+    } else {
+      b = first + sl;
+      b_prev = first + sp;
+      b_next = first + sn;
+    }
+    active = slot < n && b != BRK_LIST_SKIP; // padding entries keep groups of 8 aligned with rows of i-neighbours
+  }
   Faces f;
-  const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;
-  const bool active = b != BRK_LIST_SKIP; // padding entries keep groups of 8 aligned with rows of i-neighbours
   bool share_im = false, share_ip = false;
   if (active) {
     const Nbr nb = load_nbr(adj, b);
-    // siblings: entry slot-1 / slot+1 when they belong to this workgroup
-    const uint32_t b_prev = w > 0 ? __builtin_amdgcn_readfirstlane(id_of(slot - 1)) : 0xFFFFFFFFu;
-    const uint32_t b_next = (w + 1 < NW && slot + 1 < n) ? __builtin_amdgcn_readfirstlane(id_of(slot + 1)) : 0xFFFFFFFFu;
-    share_im = __builtin_amdgcn_readfirstlane(nb.im) == b_prev;
-    share_ip = __builtin_amdgcn_readfirstlane(nb.ip) == b_next;
     const gcptr self = scalar_base(in + (size_t)b * step);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f.own[k] = self[k * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0); // own loads are in flight before anything waits for the adjacency row
+    // siblings: entry slot-1 / slot+1 when they belong to this workgroup
+    share_im = has_prev && __builtin_amdgcn_readfirstlane(nb.im) == b_prev;
+    share_ip = has_next && __builtin_amdgcn_readfirstlane(nb.ip) == b_next;
     const gcptr p_km = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.km) * step);
     const gcptr p_kp = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.kp) * step);
     const gcptr p_jm = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.jm) * step);
     const gcptr p_jp = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.jp) * step);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f.own[k] = self[k * 64 + lane];
     f.km = p_km[7 * 64 + lane];
     f.kp = p_kp[lane];
     f.jm = p_jm[hi * 64 + 7 * 8 + lo];
@@ -212,13 +271,19 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
   if (variant == 5 || variant == 6) { // workgroups of 8 / 4 waves sharing i-faces
     const uint32_t nw = variant == 5 ? 8 : 4;
     const uint32_t wgs = (((n + nw - 1) / nw + 7) / 8) * 8;
-    if (variant == 5) {
-      if (mpi) hipLaunchKernelGGL((k_s7_wg<true, 8>), dim3(wgs), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
-      else hipLaunchKernelGGL((k_s7_wg<false, 8>), dim3(wgs), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
-    } else {
-      if (mpi) hipLaunchKernelGGL((k_s7_wg<true, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
-      else hipLaunchKernelGGL((k_s7_wg<false, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
-    }
+#define BRK_LAUNCH_WG(M, W, I) \
+  hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), 0, st, adj, in, out, step, ids, first, n, Box{}, cf)
+#define BRK_LAUNCH_WG_W(W)                               \
+  do {                                                   \
+    if (mpi && ids) BRK_LAUNCH_WG(true, W, kModeList);   \
+    else if (mpi) BRK_LAUNCH_WG(true, W, kModeRange);    \
+    else if (ids) BRK_LAUNCH_WG(false, W, kModeList);    \
+    else BRK_LAUNCH_WG(false, W, kModeRange);            \
+  } while (0)
+    if (variant == 5) BRK_LAUNCH_WG_W(8);
+    else BRK_LAUNCH_WG_W(4);
+#undef BRK_LAUNCH_WG_W
+#undef BRK_LAUNCH_WG
   } else { // variant 2: one brick per wave, every face gathered
     const uint32_t wgs = (((n + kWavesPerWG - 1) / kWavesPerWG + 7) / 8) * 8;
     if (mpi)
@@ -226,6 +291,26 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
     else
       hipLaunchKernelGGL(k_s7<false>, dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf);
   }
+  HIP_TRY(hipGetLastError());
+  return BRK_OK;
+}
+
+// Box mode (brk_stencil_apply_box): no id list; see struct Box.
+int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, double *out, size_t step, uint32_t base,
+                     const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const Coeffs &cf, hipStream_t st) {
+  Box bx{base, tot[0], tot[1], {lo[0], lo[1], lo[2]}, {cnt[0], cnt[1], cnt[2]}};
+  const uint32_t G = (cnt[0] + 7) / 8;
+  uint32_t per_xcd = 0;
+  for (uint32_t x = 0; x < 8; ++x) {
+    const uint32_t rows = (cnt[1] * (x + 1)) / 8 - (cnt[1] * x) / 8;
+    per_xcd = rows * cnt[2] * G > per_xcd ? rows * cnt[2] * G : per_xcd;
+  }
+  if (per_xcd == 0) return BRK_OK;
+  const uint32_t n = cnt[0] * cnt[1] * cnt[2];
+  if (stencil_id == BRK_MPI7)
+    hipLaunchKernelGGL((k_s7_wg<true, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+  else
+    hipLaunchKernelGGL((k_s7_wg<false, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

@@ -24,16 +24,23 @@ def stencil_iters(stencil):
     return lib.brk_stencil_iters(_sid(stencil))
 
 
-def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, coeff=None, stream=None):
+def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coeff=None, stream=None):
     """out[b] = stencil(in[b], neighbours) for b in `ids` (device int32 tensor holding uint32 brick ids, e.g.
-    the reference's `grid`) or in brick_range=(begin,end).  bIn/bOut: Brick objects sharing one BrickInfo."""
+    the reference's `grid`), in brick_range=(begin,end), or in box=(base, tot[3], lo[3], cnt[3]) of a lexicographic
+    numbering (contiguous axis first).  bIn/bOut: Brick objects sharing one BrickInfo."""
     sid = _sid(stencil)
     cp = None
     if coeff is not None:
         cbuf = np.ascontiguousarray(coeff, dtype=np.float64)
         cp = cbuf.ctypes.data_as(C.POINTER(C.c_double))
     adj = bIn.bInfo.adj
-    if ids is not None:
+    if box is not None:
+        base, tot, lo, cnt = box
+        U3 = C.c_uint32 * 3
+        check(lib.brk_stencil_apply_box(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, int(base),
+                                        U3(*[int(x) for x in tot]), U3(*[int(x) for x in lo]), U3(*[int(x) for x in cnt]),
+                                        cp, _stream(stream)))
+    elif ids is not None:
         check(lib.brk_stencil_apply_list(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids),
                                          ids.numel(), cp, _stream(stream)))
     else:

@@ -364,3 +364,39 @@ def test_full_size_512_properties(oracle, dev, name):
     oracle.brick_stencil(NAMES[name], info.adj_host, hin, want, 512, ids=sub, coeff=coeff)
     got = sx.dat.cpu().numpy().reshape(-1, 512)[sub]
     assert np.abs(got - want.reshape(-1, 512)[sub]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["7pt", "mpi7pt", "mpi13pt"])
+@pytest.mark.parametrize("shape", [(10, 10, 10), (7, 21, 5), (66, 13, 4)])
+def test_box_form(oracle, dev, name, shape):
+    """brk_stencil_apply_box: the reference launch shape (interior box of an init_grid numbering), ids derived in the
+    kernel.  Row lengths that are / are not multiples of 8, more and fewer rows than XCDs."""
+    ni, nj, nk = shape
+    grid, info = bl.init_grid(shape, dev)
+    st = bl.BrickStorage.allocate(info.nbricks, 1024, dev)
+    st.dat.uniform_(0.0, 1.0)
+    st.dat.view(-1, 1024)[:, 512:] = 0
+    coeff = oracle.coeffs(129, 1) if name in ("7pt", "27pt") else None
+    bl.apply_stencil(name, bl.Brick(info, st, 0), bl.Brick(info, st, 512), box=(0, shape, (1, 1, 1), (ni - 2, nj - 2, nk - 2)),
+                     coeff=coeff)
+    ids = np.ascontiguousarray(grid.reshape(nk, nj, ni)[1:-1, 1:-1, 1:-1]).reshape(-1)
+    hin = np.ascontiguousarray(st.dat.cpu().numpy().reshape(-1, 1024)[:, :512]).reshape(-1)
+    want = np.zeros_like(hin)
+    oracle.brick_stencil(NAMES[name], info.adj_host, hin, want, 512, ids=ids, coeff=coeff)
+    got = st.dat.cpu().numpy().reshape(-1, 1024)[:, 512:]
+    assert np.abs(got - want.reshape(-1, 512)).max() <= TOL
+
+
+def test_box_form_decomp_inner(oracle, dev):
+    """inner region [1,sep0) of a BrickDecomp as a box (base 1)"""
+    d = bl.BrickDecomp((48, 40, 56))
+    info = d.getBrickInfo(dev)
+    A, B = info.allocate(512, dev), info.allocate(512, dev)
+    A.dat.uniform_(0.0, 1.0)
+    A.dat[:512] = 0
+    nb = [x // 8 - 2 for x in (48, 40, 56)]
+    bl.apply_stencil("mpi7pt", bl.Brick(info, A, 0), bl.Brick(info, B, 0), box=(1, nb, (0, 0, 0), nb))
+    hin = A.dat.cpu().numpy()
+    want = np.zeros_like(hin)
+    oracle.brick_stencil(ST_MPI7, d.adj, hin, want, 512, n=d.sep_pos[0] - 1, first=1)
+    assert np.abs(B.dat.cpu().numpy() - want).max() <= TOL

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_stream2_persist(const double *in, doubl
 
 int main(int argc, char **argv) {
   int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1;
-  bool decomp = false, shuffle = false, separate = false, stream = false;
+  bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false;
   std::vector<int> variants = {1, 2, 5};
   for (int a = 1; a < argc; ++a) {
     std::string o = argv[a];
@@ -139,6 +139,7 @@ int main(int argc, char **argv) {
     else if (o == "-i") iters = atoi(argv[++a]);
     else if (o == "-d") decomp = true;
     else if (o == "-r") shuffle = true;
+    else if (o == "-b") boxmode = true;     // brk_stencil_apply_box over the interior (lexi layouts only)
     else if (o == "-S") separate = true;   // lexicographic list but two storages (step 512)
     else if (o == "-o") order = atoi(argv[++a]); // 0 lexi; J>0: per-XCD j-slabs of 8 rows, swept in sub-blocks of J rows over all k
     else if (o == "-k") kstack = atoi(argv[++a]); // with -o: workgroup = 8 i-bricks x kstack k-levels
@@ -227,7 +228,10 @@ int main(int argc, char **argv) {
   double *ref_out = (decomp || separate) ? st_ref : st_ref + 512;
 
   auto launch = [&](double *out) {
-    if (ids_d)
+    if (boxmode && !decomp) {
+      uint32_t SBu = (uint32_t)(N / 8 + 2), tot[3] = {SBu, SBu, SBu}, lo3[3] = {1, 1, 1}, cnt[3] = {SBu - 2, SBu - 2, SBu - 2};
+      BK(brk_stencil_apply_box(sid, adj_d, st_in, out, step, 0, tot, lo3, cnt, cp, nullptr));
+    } else if (ids_d)
       BK(brk_stencil_apply_list(sid, adj_d, st_in, out, step, ids_d, nlist, cp, nullptr));
     else
       BK(brk_stencil_apply_range(sid, adj_d, st_in, out, step, first, first + nlist, cp, nullptr));
