@@ -334,6 +334,45 @@ void orc_array_stencil(int id, const double *in, double *out, const long ext[3],
       }
 }
 
+/* 7-point sweeps without the tile gather: rows of 8 are processed straight from the brick and its six face neighbours
+ * (same accessor semantics, same term order as stencil_point, so results are bit-identical to the generic path; this
+ * is only the faster formulation used for the cpu_baseline timing: contiguous 8-wide inner loop the compiler vectorises). */
+static void brick_stencil_star7(int id, const uint32_t *adj, const double *in, double *out, size_t step,
+                                const uint32_t *ids, long n, uint32_t first, const double *c) {
+#pragma omp parallel for schedule(static)
+  for (long q = 0; q < n; ++q) {
+    uint32_t b = ids ? ids[q] : (uint32_t)(first + q);
+    const uint32_t *a = adj + (size_t)b * 27;
+    const double *src = in + (size_t)b * step;
+    const double *km = in + (size_t)a[4] * step, *kp = in + (size_t)a[22] * step;
+    const double *jm = in + (size_t)a[10] * step, *jp = in + (size_t)a[16] * step;
+    const double *im = in + (size_t)a[12] * step, *ip = in + (size_t)a[14] * step;
+    double *dst = out + (size_t)b * step;
+    for (int k = 0; k < BS; ++k)
+      for (int j = 0; j < BS; ++j) {
+        const double *cc = src + k * 64 + j * 8;
+        const double *up = k < 7 ? cc + 64 : kp + j * 8;
+        const double *dn = k > 0 ? cc - 64 : km + 7 * 64 + j * 8;
+        const double *jn = j < 7 ? cc + 8 : jp + k * 64;
+        const double *js = j > 0 ? cc - 8 : jm + k * 64 + 56;
+        double row[10];
+        row[0] = im[k * 64 + j * 8 + 7];
+        for (int i = 0; i < 8; ++i) row[i + 1] = cc[i];
+        row[9] = ip[k * 64 + j * 8];
+        double *o = dst + k * 64 + j * 8;
+        if (id == ORC_7PT_COEFF) {
+#pragma omp simd
+          for (int i = 0; i < 8; ++i)
+            o[i] = c[5] * up[i] + c[6] * dn[i] + c[3] * jn[i] + c[4] * js[i] + c[1] * row[i + 2] + c[2] * row[i] + c[0] * row[i + 1];
+        } else {
+#pragma omp simd
+          for (int i = 0; i < 8; ++i)
+            o[i] = (up[i] + dn[i] + jn[i] + js[i] + row[i + 2] + row[i]) * c[1] + row[i + 1] * c[0];
+        }
+      }
+  }
+}
+
 /* Brick sweep over a list of brick ids (or the range [0,n) + first when ids == NULL).
  * Semantics = naive accessor form (ref: stencils/3axis.cpp:51-66,205-235, weak/main.cpp:26-36):
  * every tap is bIn[b][k+dk][j+dj][i+di] through the adjacency list.  Implemented by gathering
@@ -343,6 +382,10 @@ void orc_brick_stencil(int id, const uint32_t *adj, const double *in, double *ou
                        const uint32_t *ids, long n, uint32_t first, const double *coeff) {
   if (!coeff)
     coeff = orc_stencil_default_coeff(id);
+  if (id == ORC_7PT_COEFF || id == ORC_MPI7) {
+    brick_stencil_star7(id, adj, in, out, step, ids, n, first, coeff);
+    return;
+  }
   const int R = orc_stencil_radius(id);
   const int star = orc_stencil_is_star(id);
   const int T = BS + 2 * R;
