@@ -168,8 +168,10 @@ def run_weak(args, bl, dev, rank, world):
     comm = torch.cuda.Stream()
     overlap = not args.no_overlap
 
+    state = {}
+
     def step():
-        return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=comm, overlap=overlap, lists=lists)
+        return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=comm, overlap=overlap, lists=lists, state=state)
 
     S = bl.stencil_iters(sid)
     for _ in range(W):

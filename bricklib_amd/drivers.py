@@ -23,10 +23,13 @@ class SweepLists:
             setattr(self, name, grid_to_device(ids, device))
 
 
-def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, overlap=True, lists=None):
+def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, overlap=True, lists=None, state=None):
     """A, B: Brick objects over two storages built from decomposition `d`; exchange(stream) refreshes A's ghosts.
     main/comm: torch streams (default: current stream, no overlap).  lists: SweepLists(d) (optional; without it the
-    sweeps run over plain id ranges)."""
+    sweeps run over plain id ranges).  state: dict carried from one cycle to the next (optional): the last sweep writes
+    the surface bricks first and records an event, so that the NEXT cycle's exchange can start while the inner bricks
+    of the last sweep -- and then of the first sweep -- are still being computed (the exchange only reads surface bricks
+    of A and writes ghost bricks of A, which the last sweep neither writes nor reads)."""
     S = stencil_iters(stencil)
     sep0, sep1, sep2 = d.sep_pos
     main = main or torch.cuda.current_stream()
@@ -35,15 +38,18 @@ def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, ove
         if lists is not None:
             apply_stencil(stencil, src, dst, ids=getattr(lists, which), coeff=coeff, stream=main)
         else:
-            rng = {"inner": (1, sep0), "shell": (sep0, sep2), "all": (1, sep2), "domain": (1, sep1)}[which]
+            rng = {"inner": (1, sep0), "shell": (sep0, sep2), "surface": (sep0, sep1), "all": (1, sep2),
+                   "domain": (1, sep1)}[which]
             apply_stencil(stencil, src, dst, brick_range=rng, coeff=coeff, stream=main)
 
     if comm is None or not overlap:
         exchange(main)
         sweep(A, B, "all")
     else:
-        ev0 = torch.cuda.Event()
-        ev0.record(main)                 # A as left by the previous cycle
+        ev0 = state.pop("surface_done", None) if state is not None else None
+        if ev0 is None:
+            ev0 = torch.cuda.Event()
+            ev0.record(main)             # A as left by the previous cycle
         comm.wait_event(ev0)
         exchange(comm)                   # ghosts of A arrive on the comm stream ...
         ev1 = torch.cuda.Event()
@@ -54,5 +60,12 @@ def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, ove
     for _ in range(S // 2 - 1):
         sweep(B, A, "all")
         sweep(A, B, "all")
-    sweep(B, A, "domain")
+    if state is not None and comm is not None and overlap:
+        sweep(B, A, "surface")           # what the next exchange sends ...
+        ev = torch.cuda.Event()
+        ev.record(main)
+        state["surface_done"] = ev
+        sweep(B, A, "inner")             # ... is ready before the bulk of the last sweep
+    else:
+        sweep(B, A, "domain")
     return S

@@ -400,3 +400,31 @@ def test_box_form_decomp_inner(oracle, dev):
     want = np.zeros_like(hin)
     oracle.brick_stencil(ST_MPI7, d.adj, hin, want, 512, n=d.sep_pos[0] - 1, first=1)
     assert np.abs(B.dat.cpu().numpy() - want).max() <= TOL
+
+
+def test_weak_cycle_overlap_streams_single_rank(oracle, dev):
+    """The overlapped schedule (exchange on a second stream, surface-first last sweep, event hand-over between cycles)
+    gives the same field as the plain in-order schedule."""
+    from bricklib_amd.decomp import Exchanger
+    from bricklib_amd.drivers import SweepLists
+    dom = (64, 48, 56)
+    d = bl.BrickDecomp(dom)
+    bl.populate(d, [1, 1, 1], [0, 0, 0])
+    info = d.getBrickInfo(dev)
+    res = []
+    for mode in ("plain", "overlap"):
+        torch.manual_seed(3)
+        stA, stB = info.allocate(512, dev), info.allocate(512, dev)
+        stA.dat.uniform_(0.0, 1.0)
+        A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
+        ex = Exchanger(d, stA, 0)
+        lists = SweepLists(d, dev)
+        main, comm, state = torch.cuda.current_stream(), torch.cuda.Stream(), {}
+        for _ in range(3):
+            if mode == "plain":
+                weak_cycle("mpi7pt", d, A, B, ex.exchange, lists=lists)
+            else:
+                weak_cycle("mpi7pt", d, A, B, ex.exchange, main=main, comm=comm, overlap=True, lists=lists, state=state)
+        torch.cuda.synchronize()
+        res.append(stA.dat[512 * 1:512 * d.sep_pos[1]].clone())
+    assert torch.equal(res[0], res[1])
