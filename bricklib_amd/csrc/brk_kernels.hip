@@ -134,19 +134,19 @@ __global__ __launch_bounds__(kWG) void k_iter(IterGeom g, double *__restrict__ a
   }
 }
 
-int g_variant[BRK_NSTENCIL] = {0, 0, 0, 0, 0, 0};
+int g_variant[BRK_NSTENCIL] = {0, 0, 0, 0, 0, 0, 0};
 constexpr int kDefaultStar7Variant = 5; // 8-wave workgroups sharing i-faces through LDS (brk_star7.hip)
 
 // defaults: stencils/fake.h:11-33
 const double kDefault[BRK_NSTENCIL][10] = {{0}, {0}, {0.4, 0.1}, {0.4, 0.07, 0.03}, {0.1, 0.06, 0.045, 0.03, 0.015},
-                                           {0.1, 0.04, 0.03, 0.01, 0.006, 0.004, 0.005, 0.002, 0.003, 0.001}};
+                                           {0.1, 0.04, 0.03, 0.01, 0.006, 0.004, 0.005, 0.002, 0.003, 0.001}, {0}};
 
 int make_coeffs(int id, const double *host, Coeffs &cf) {
   std::memset(&cf, 0, sizeof cf);
   const int nc = brk_stencil_ncoeff(id);
   if (nc < 0) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
   if (!host) {
-    if (id == BRK_7PT_COEFF || id == BRK_27PT_COEFF)
+    if (id == BRK_7PT_COEFF || id == BRK_27PT_COEFF || id == BRK_COND7)
       return brk_fail(BRK_EINVAL, "stencil %d needs a coefficient vector", id);
     host = kDefault[id];
   }
@@ -175,7 +175,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   const dim3 grid(((wgs + 7) / 8) * 8), block(kWG);
   hipStream_t st = static_cast<hipStream_t>(s);
   // 7-point sweeps: specialised kernels (brk_star7.hip) unless variant 1 (generic star kernel) is requested
-  if ((id == BRK_7PT_COEFF || id == BRK_MPI7) && g_variant[id] != 1)
+  if ((id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) && g_variant[id] != 1)
     return launch_star7(id, g_variant[id] == 0 ? kDefaultStar7Variant : g_variant[id], adj, in, out, step, ids, first, n, cf, st);
   if ((id == BRK_MPI13 || id == BRK_MPI25) && g_variant[id] != 1) return launch_star_wg(id, adj, in, out, step, ids, first, n, cf, st);
   // 27-pt: shared i-halos (0.57 -> 0.54 ms at 512^3).  125-pt is fp64-VALU/LDS bound (1000 FMAs + 300 ds_reads per lane per
@@ -185,6 +185,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
     return launch_cube_wg(id, adj, in, out, step, ids, first, n, cf, st);
   switch (id) {
   case BRK_7PT_COEFF: hipLaunchKernelGGL(k_star<kStar7Coeff>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
+  case BRK_COND7: hipLaunchKernelGGL(k_star<kStarCond7>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_MPI7: hipLaunchKernelGGL(k_star<kStarMpi7>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_MPI13: hipLaunchKernelGGL(k_star<kStarMpi13>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_MPI25: hipLaunchKernelGGL(k_star<kStarMpi25>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
@@ -254,7 +255,7 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
   if ((uint64_t)cnt[0] * cnt[1] * cnt[2] == 0) return BRK_OK;
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
-  if (id == BRK_7PT_COEFF || id == BRK_MPI7)
+  if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7)
     return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s));
   // other stencils: no arithmetic walk yet -- sweep the box row by row through the range form (rows are contiguous ids)
   for (uint32_t k = 0; k < cnt[2]; ++k)

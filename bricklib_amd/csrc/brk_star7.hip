@@ -84,7 +84,28 @@ __device__ __forceinline__ void stage(double *tile, const Faces &f, int lane) {
   tile[hi * kPlane + 88 + lo] = f.ip;
 }
 
-template <bool MPI>
+template <int KIND>
+__device__ __forceinline__ double point7(double kp, double km, double jp, double jm, double ip, double im, double c0,
+                                         const Coeffs &cf);
+// KIND: 0 = coefficient form (7pt.py), 1 = alpha/beta form (mpi7pt.py), 2 = d3cond (cond.py)
+enum { kCoeff = 0, kMpi = 1, kCond = 2 };
+
+template <int KIND>
+__device__ __forceinline__ double point7(double kp, double km, double jp, double jm, double ip, double im, double c0,
+                                         const Coeffs &cf) {
+  if (KIND == kMpi) // stencils/fake.h:346-349
+    return (kp + km + jp + jm + ip + im) * cf.c[1] + c0 * cf.c[0];
+  if (KIND == kCond) { // stencils/3axis.cpp:104-111: taps clipped at zero, absolute value of the sum
+    auto pos = [](double x) { return x > 0.0 ? x : 0.0; };
+    const double p = cf.c[5] * pos(kp) + cf.c[6] * pos(km) + cf.c[3] * pos(jp) + cf.c[4] * pos(jm) + cf.c[1] * pos(ip) +
+                     cf.c[2] * pos(im) + cf.c[0] * pos(c0);
+    return p > 0 ? p : -p;
+  }
+  // stencils/3axis.cpp:60-63 term order
+  return cf.c[5] * kp + cf.c[6] * km + cf.c[3] * jp + cf.c[4] * jm + cf.c[1] * ip + cf.c[2] * im + cf.c[0] * c0;
+}
+
+template <int MPI>
 __device__ __forceinline__ void compute_store(const double *tile, const Faces &f, double *dst_, int lane,
                                               const Coeffs &cf) {
   const int hi = lane >> 3, lo = lane & 7;
@@ -102,16 +123,13 @@ __device__ __forceinline__ void compute_store(const double *tile, const Faces &f
     const double km = k == 0 ? f.km : f.own[k > 0 ? k - 1 : 0];
     const double kp = k == 7 ? f.kp : f.own[k < 7 ? k + 1 : 7];
     double res;
-    if (MPI) // stencils/fake.h:346-349
-      res = (kp + km + jp + jm + ip + im) * cf.c[1] + c0 * cf.c[0];
-    else     // stencils/3axis.cpp:60-63 term order
-      res = cf.c[5] * kp + cf.c[6] * km + cf.c[3] * jp + cf.c[4] * jm + cf.c[1] * ip + cf.c[2] * im + cf.c[0] * c0;
+    res = point7<MPI>(kp, km, jp, jm, ip, im, c0, cf);
     dst[k * 64 + lane] = res;
   }
 }
 
 // ---- variant 2: one brick per wave ------------------------------------------------------------------------------
-template <bool MPI>
+template <int MPI>
 __global__ __launch_bounds__(kWG, 6) void k_s7(const uint32_t *__restrict__ adj, const double *__restrict__ in,
                                                 double *__restrict__ out, size_t step,
                                                 const uint32_t *__restrict__ ids, uint32_t first, uint32_t n,
@@ -175,7 +193,7 @@ __device__ __forceinline__ bool box_entry(const Box &bx, uint32_t x, uint32_t g,
   return true;
 }
 
-template <bool MPI, int NW, int MODE>
+template <int MPI, int NW, int MODE>
 __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uint32_t *__restrict__ adj,
                                                                       const double *__restrict__ in,
                                                                       double *__restrict__ out, size_t step,
@@ -255,10 +273,7 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
     const double km = k == 0 ? f.km : f.own[k > 0 ? k - 1 : 0];
     const double kp = k == 7 ? f.kp : f.own[k < 7 ? k + 1 : 7];
     double res;
-    if (MPI)
-      res = (kp + km + jp + jm + ip + im) * cf.c[1] + c0 * cf.c[0];
-    else
-      res = cf.c[5] * kp + cf.c[6] * km + cf.c[3] * jp + cf.c[4] * jm + cf.c[1] * ip + cf.c[2] * im + cf.c[0] * c0;
+    res = point7<MPI>(kp, km, jp, jm, ip, im, c0, cf);
     dst[k * 64 + lane] = res;
   }
 }
@@ -267,29 +282,36 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
 
 int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step,
                  const uint32_t *ids, uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
-  const bool mpi = stencil_id == BRK_MPI7;
+  const int kind = stencil_id == BRK_MPI7 ? kMpi : (stencil_id == BRK_COND7 ? kCond : kCoeff);
   if (variant == 5 || variant == 6) { // workgroups of 8 / 4 waves sharing i-faces
     const uint32_t nw = variant == 5 ? 8 : 4;
     const uint32_t wgs = (((n + nw - 1) / nw + 7) / 8) * 8;
 #define BRK_LAUNCH_WG(M, W, I) \
   hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), 0, st, adj, in, out, step, ids, first, n, Box{}, cf)
-#define BRK_LAUNCH_WG_W(W)                               \
-  do {                                                   \
-    if (mpi && ids) BRK_LAUNCH_WG(true, W, kModeList);   \
-    else if (mpi) BRK_LAUNCH_WG(true, W, kModeRange);    \
-    else if (ids) BRK_LAUNCH_WG(false, W, kModeList);    \
-    else BRK_LAUNCH_WG(false, W, kModeRange);            \
+#define BRK_LAUNCH_WG_K(K, W)                      \
+  do {                                            \
+    if (ids) BRK_LAUNCH_WG(K, W, kModeList);      \
+    else BRK_LAUNCH_WG(K, W, kModeRange);         \
+  } while (0)
+#define BRK_LAUNCH_WG_W(W)                        \
+  do {                                            \
+    if (kind == kMpi) BRK_LAUNCH_WG_K(kMpi, W);   \
+    else if (kind == kCond) BRK_LAUNCH_WG_K(kCond, W); \
+    else BRK_LAUNCH_WG_K(kCoeff, W);              \
   } while (0)
     if (variant == 5) BRK_LAUNCH_WG_W(8);
     else BRK_LAUNCH_WG_W(4);
 #undef BRK_LAUNCH_WG_W
+#undef BRK_LAUNCH_WG_K
 #undef BRK_LAUNCH_WG
   } else { // variant 2: one brick per wave, every face gathered
     const uint32_t wgs = (((n + kWavesPerWG - 1) / kWavesPerWG + 7) / 8) * 8;
-    if (mpi)
-      hipLaunchKernelGGL(k_s7<true>, dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf);
+    if (kind == kMpi)
+      hipLaunchKernelGGL(k_s7<kMpi>, dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf);
+    else if (kind == kCond)
+      hipLaunchKernelGGL(k_s7<kCond>, dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf);
     else
-      hipLaunchKernelGGL(k_s7<false>, dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf);
+      hipLaunchKernelGGL(k_s7<kCoeff>, dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf);
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;
@@ -308,9 +330,11 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
   if (per_xcd == 0) return BRK_OK;
   const uint32_t n = cnt[0] * cnt[1] * cnt[2];
   if (stencil_id == BRK_MPI7)
-    hipLaunchKernelGGL((k_s7_wg<true, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+    hipLaunchKernelGGL((k_s7_wg<kMpi, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+  else if (stencil_id == BRK_COND7)
+    hipLaunchKernelGGL((k_s7_wg<kCond, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
   else
-    hipLaunchKernelGGL((k_s7_wg<false, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+    hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

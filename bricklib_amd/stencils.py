@@ -8,7 +8,7 @@ from .brick import _ptr, _stream
 
 # name -> id; names follow the reference's stencil scripts (stencils/*.py) and drivers
 STENCILS = {"7pt": BRK_7PT_COEFF, "27pt": BRK_27PT_COEFF, "mpi7pt": BRK_MPI7, "mpi13pt": BRK_MPI13,
-            "mpi25pt": BRK_MPI25, "mpi125pt": BRK_MPI125}
+            "mpi25pt": BRK_MPI25, "mpi125pt": BRK_MPI125, "cond": 6}
 
 
 def _sid(stencil):

@@ -5,6 +5,7 @@
 //   (2) one call of the C ABI, brk_stencil_apply_list, over the same `grid` entries (the fast path).
 // Both are checked with compareBrick against the array sweep on the CPU, like the reference does.
 //   build: make -C examples        run: examples/single_hip [N]
+#include <algorithm>
 #include <cstdio>
 #include <iostream>
 #include <vector>
@@ -50,6 +51,15 @@ __global__ void d3pt7_brick_trans(unsigned (*grid)[STRIDEB][STRIDEB], BrickDev b
   brick("7pt.py", VSVEC, (BDIM), (VFOLD), b);
 }
 
+// d3cond_brick_trans of the reference (stencils/3axis.hip.cpp:214-223): same shape, "cond.py"
+__global__ void d3cond_brick_trans(unsigned (*grid)[STRIDEB][STRIDEB], BrickDev bIn, BrickDev bOut, bElem *coeff) {
+  long tk = GB + hipBlockIdx_z;
+  long tj = GB + hipBlockIdx_y;
+  long ti = GB + hipBlockIdx_x;
+  unsigned b = grid[tk][tj][ti];
+  brick("cond.py", VSVEC, (BDIM), (VFOLD), b);
+}
+
 int main() {
   bElem *coeff = (bElem *)malloc(COEFF_SIZE * sizeof(bElem));
   {
@@ -68,6 +78,7 @@ int main() {
 
   brkSeed(7);
   bElem *in_ptr = randomArray({STRIDE, STRIDE, STRIDE});
+  for (long l = 0; l < (long)STRIDE * STRIDE * STRIDE; ++l) in_ptr[l] -= 0.5; // sign changes, so that d3cond's max() matters
   bElem *out_ptr = zeroArray({STRIDE, STRIDE, STRIDE});
   auto arr_in = (bElem(*)[STRIDE][STRIDE])in_ptr;
   auto arr_out = (bElem(*)[STRIDE][STRIDE])out_ptr;
@@ -129,6 +140,26 @@ int main() {
     }
     gpuCheck(hipDeviceSynchronize());
     check("brk_stencil_apply_list");
+  }
+  // (3) d3cond (stencils/3axis.cpp:94-163): |sum c*max(in,0)|, reference-shaped kernel with the rewritten brick("cond.py")
+  {
+    using std::max;
+#pragma omp parallel for collapse(2)
+    for (long k = PADDING + GZ; k < PADDING + GZ + N; ++k)
+      for (long j = PADDING + GZ; j < PADDING + GZ + N; ++j)
+        for (long i = PADDING + GZ; i < PADDING + GZ + N; ++i) {
+          bElem partial = coeff[5] * max(arr_in[k + 1][j][i], 0.0) + coeff[6] * max(arr_in[k - 1][j][i], 0.0) +
+                          coeff[3] * max(arr_in[k][j + 1][i], 0.0) + coeff[4] * max(arr_in[k][j - 1][i], 0.0) +
+                          coeff[1] * max(arr_in[k][j][i + 1], 0.0) + coeff[2] * max(arr_in[k][j][i - 1], 0.0) +
+                          coeff[0] * max(arr_in[k][j][i], 0.0);
+          arr_out[k][j][i] = partial > 0 ? partial : -partial;
+        }
+    BrickDev dIn{binfo_dev, bstorage_dev.dat.get(), bstorage_dev.step};
+    BrickDev dOut{binfo_dev, bstorage_dev.dat.get() + bsize, bstorage_dev.step};
+    dim3 block(NB, NB, NB), thread(64);
+    hipLaunchKernelGGL(d3cond_brick_trans, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
+    gpuCheck(hipDeviceSynchronize());
+    check("brick() cond kernel");
   }
   return 0;
 }

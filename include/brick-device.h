@@ -48,7 +48,7 @@ struct StarTile {
   __device__ static constexpr int ti(int k, int j, int ii) { return TJ_ELEMS + (k * 8 + j) * PI + ii; }
 };
 
-enum StarKind { kStar7Coeff, kStarMpi7, kStarMpi13, kStarMpi25 };
+enum StarKind { kStar7Coeff, kStarMpi7, kStarMpi13, kStarMpi25, kStarCond7 };
 
 template <int KIND>
 struct StarTraits;
@@ -56,6 +56,7 @@ template <> struct StarTraits<kStar7Coeff> { static constexpr int R = 1; };
 template <> struct StarTraits<kStarMpi7> { static constexpr int R = 1; };
 template <> struct StarTraits<kStarMpi13> { static constexpr int R = 2; };
 template <> struct StarTraits<kStarMpi25> { static constexpr int R = 4; };
+template <> struct StarTraits<kStarCond7> { static constexpr int R = 1; };
 
 // One wave computes brick `b` (wave-uniform).  `tile` = this wave's private LDS slice of StarTile<R>::ELEMS doubles.
 template <int KIND>
@@ -129,6 +130,12 @@ __device__ __forceinline__ void star_brick(double *tile, const uint32_t *__restr
       // stencils/3axis.cpp:60-63 term order
       res = cf.c[5] * col[R + k + 1] + cf.c[6] * col[R + k - 1] + cf.c[3] * jp[0] + cf.c[4] * jm[0] +
             cf.c[1] * ip[0] + cf.c[2] * im[0] + cf.c[0] * c0;
+    } else if (KIND == kStarCond7) {
+      // stencils/3axis.cpp:104-111 (d3cond): taps clipped at zero, absolute value of the sum
+      auto pos = [](double x) { return x > 0.0 ? x : 0.0; };
+      const double partial = cf.c[5] * pos(col[R + k + 1]) + cf.c[6] * pos(col[R + k - 1]) + cf.c[3] * pos(jp[0]) +
+                             cf.c[4] * pos(jm[0]) + cf.c[1] * pos(ip[0]) + cf.c[2] * pos(im[0]) + cf.c[0] * pos(c0);
+      res = partial > 0 ? partial : -partial;
     } else if (KIND == kStarMpi7) {
       // stencils/fake.h:346-349
       res = (col[R + k + 1] + col[R + k - 1] + jp[0] + jm[0] + ip[0] + im[0]) * cf.c[1] + c0 * cf.c[0];
@@ -361,14 +368,14 @@ __device__ __forceinline__ void brick_apply(const uint32_t *adj, const double *i
   Coeffs cf;
   if (coeff == nullptr) { // MPI_* constants of the reference's stencils/fake.h:11-33
     constexpr double dflt[BRK_NSTENCIL][10] = {{0}, {0}, {0.4, 0.1}, {0.4, 0.07, 0.03}, {0.1, 0.06, 0.045, 0.03, 0.015},
-                                               {0.1, 0.04, 0.03, 0.01, 0.006, 0.004, 0.005, 0.002, 0.003, 0.001}};
+                                               {0.1, 0.04, 0.03, 0.01, 0.006, 0.004, 0.005, 0.002, 0.003, 0.001}, {0}};
     for (int s = 0; s < 10; ++s) cf.c[s] = dflt[STENCIL][s];
   } else if (STENCIL == BRK_27PT_COEFF) {
     for (int s = 0; s < 27; ++s) cf.c[s] = coeff[s];
     cf.c[adj_slot(0, 1, 0)] = 0.0;                 // reference quirk, stencils/3axis.cpp:195,225
     cf.c[adj_slot(1, 1, 0)] = coeff[16] + coeff[25];
   } else {
-    constexpr int nc = STENCIL == BRK_7PT_COEFF ? 7 : (STENCIL == BRK_MPI7 ? 2 : (STENCIL == BRK_MPI13 ? 3 : (STENCIL == BRK_MPI25 ? 5 : 10)));
+    constexpr int nc = (STENCIL == BRK_7PT_COEFF || STENCIL == BRK_COND7) ? 7 : (STENCIL == BRK_MPI7 ? 2 : (STENCIL == BRK_MPI13 ? 3 : (STENCIL == BRK_MPI25 ? 5 : 10)));
     for (int s = 0; s < nc; ++s) cf.c[s] = coeff[s];
   }
   if (STENCIL == BRK_27PT_COEFF || STENCIL == BRK_MPI125) {
@@ -376,7 +383,7 @@ __device__ __forceinline__ void brick_apply(const uint32_t *adj, const double *i
     __shared__ double lds[MAXW * CubeTile<CubeTraits<KIND>::R>::ELEMS];
     cube_brick<KIND>(lds + wave * CubeTile<CubeTraits<KIND>::R>::ELEMS, adj, in, out, step, b, cf, lane);
   } else {
-    constexpr int KIND = STENCIL == BRK_7PT_COEFF ? kStar7Coeff : (STENCIL == BRK_MPI7 ? kStarMpi7 : (STENCIL == BRK_MPI13 ? kStarMpi13 : kStarMpi25));
+    constexpr int KIND = STENCIL == BRK_7PT_COEFF ? kStar7Coeff : (STENCIL == BRK_COND7 ? kStarCond7 : (STENCIL == BRK_MPI7 ? kStarMpi7 : (STENCIL == BRK_MPI13 ? kStarMpi13 : kStarMpi25)));
     __shared__ double lds[MAXW * StarTile<StarTraits<KIND>::R>::ELEMS];
     star_brick<KIND>(lds + wave * StarTile<StarTraits<KIND>::R>::ELEMS, adj, in, out, step, b, cf, lane);
   }

@@ -47,8 +47,9 @@ enum {
  *  BRK_MPI7   {ALPHA,BETA}      stencils/mpi7pt.py, stencils/fake.h:11-12,346-353   (NULL -> .4,.1)
  *  BRK_MPI13  {B0,B1,B2}        stencils/mpi13pt.py, fake.h:20-22,71-84             (NULL -> defaults)
  *  BRK_MPI25  {A0..A4}          stencils/mpi25pt.py, fake.h:14-18,41-70             (NULL -> defaults)
- *  BRK_MPI125 {C0..C9}          stencils/mpi125pt.py, fake.h:24-33,90-343           (NULL -> defaults) */
-enum { BRK_7PT_COEFF = 0, BRK_27PT_COEFF = 1, BRK_MPI7 = 2, BRK_MPI13 = 3, BRK_MPI25 = 4, BRK_MPI125 = 5, BRK_NSTENCIL = 6 };
+ *  BRK_MPI125 {C0..C9}          stencils/mpi125pt.py, fake.h:24-33,90-343           (NULL -> defaults)
+ *  BRK_COND7  coeff[0..6]       stencils/cond.py, stencils/3axis.cpp:94-163 (d3cond): |sum c_t * max(in_t, 0)| */
+enum { BRK_7PT_COEFF = 0, BRK_27PT_COEFF = 1, BRK_MPI7 = 2, BRK_MPI13 = 3, BRK_MPI25 = 4, BRK_MPI125 = 5, BRK_COND7 = 6, BRK_NSTENCIL = 7 };
 
 const char *brk_last_error(void);
 /* 7*1000+... style version of this ABI */

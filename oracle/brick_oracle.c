@@ -26,7 +26,7 @@
 #define BELEMS 512      /* 8*8*8 */
 
 /* stencil ids -- identical to include/brk.h */
-enum { ORC_7PT_COEFF = 0, ORC_27PT_COEFF = 1, ORC_MPI7 = 2, ORC_MPI13 = 3, ORC_MPI25 = 4, ORC_MPI125 = 5 };
+enum { ORC_7PT_COEFF = 0, ORC_27PT_COEFF = 1, ORC_MPI7 = 2, ORC_MPI13 = 3, ORC_MPI25 = 4, ORC_MPI125 = 5, ORC_COND7 = 6 };
 
 /* ------------------------------------------------------------------------------------------
  * Deterministic inputs.  The reference seeds from random_device (ref: src/multiarray.cpp:13-23,
@@ -210,6 +210,7 @@ double orc_maxdiff_brick(const long dimlist[3], const long padding[3], const lon
  *  ORC_MPI7      : ref stencils/fake.h:346-349  (sum of 6)*BETA + c*ALPHA
  *  ORC_MPI13     : ref stencils/fake.h:71-77
  *  ORC_MPI25     : ref stencils/fake.h:41-53
+ *  ORC_COND7     : ref stencils/3axis.cpp:104-111,137-146 (d3cond): |sum c_t * max(in_t, 0)|, 7-pt term order
  *  ORC_MPI125    : ref stencils/fake.h:90-215  (per-class sums times C0..C9; class = sorted
  *                  |offset| triple, stencils/mpi125pt.py:12-33)
  * The point function works on any array with strides (1, sj, sk).
@@ -227,11 +228,12 @@ int orc_stencil_radius(int id) {
   case ORC_MPI13: return 2;
   case ORC_MPI25: return 4;
   case ORC_MPI125: return 2;
+  case ORC_COND7: return 1;
   }
   return -1;
 }
 
-int orc_stencil_is_star(int id) { return id == ORC_7PT_COEFF || id == ORC_MPI7 || id == ORC_MPI13 || id == ORC_MPI25; }
+int orc_stencil_is_star(int id) { return id == ORC_7PT_COEFF || id == ORC_MPI7 || id == ORC_MPI13 || id == ORC_MPI25 || id == ORC_COND7; }
 
 int orc_stencil_ncoeff(int id) {
   switch (id) {
@@ -241,6 +243,7 @@ int orc_stencil_ncoeff(int id) {
   case ORC_MPI13: return 3;
   case ORC_MPI25: return 5;
   case ORC_MPI125: return 10;
+  case ORC_COND7: return 7;
   }
   return -1;
 }
@@ -277,6 +280,13 @@ static inline double stencil_point(int id, const double *p, long sj, long sk, co
   case ORC_7PT_COEFF:
     return c[5] * AT(1, 0, 0) + c[6] * AT(-1, 0, 0) + c[3] * AT(0, 1, 0) + c[4] * AT(0, -1, 0) +
            c[1] * AT(0, 0, 1) + c[2] * AT(0, 0, -1) + c[0] * AT(0, 0, 0);
+  case ORC_COND7: {
+#define POS(x) ((x) > 0.0 ? (x) : 0.0)
+    double partial = c[5] * POS(AT(1, 0, 0)) + c[6] * POS(AT(-1, 0, 0)) + c[3] * POS(AT(0, 1, 0)) + c[4] * POS(AT(0, -1, 0)) +
+                     c[1] * POS(AT(0, 0, 1)) + c[2] * POS(AT(0, 0, -1)) + c[0] * POS(AT(0, 0, 0));
+#undef POS
+    return partial > 0 ? partial : -partial;
+  }
   case ORC_27PT_COEFF:
     return c[0] * AT(-1, -1, -1) + c[1] * AT(-1, -1, 0) + c[2] * AT(-1, -1, 1) +
            c[3] * AT(-1, 0, -1) + c[4] * AT(-1, 0, 0) + c[5] * AT(-1, 0, 1) +

@@ -90,6 +90,13 @@ def main():
          arr7_sha=np.frombuffer(bytes.fromhex(sha(arr7)), dtype=np.uint8),
          cmp_eps=np.array([0.0, 1e-7, 1e-5]), cmp_verdict=np.array(verdicts, dtype=np.int32))
 
+    # ---- d3cond (stencils/3axis.cpp:94-163) on a sign-changing field: input = U[0,1) - 0.5
+    binc = bin_ - 0.5
+    outc = np.zeros(nb * 512)
+    R.brick_cond(adj, binc, outc, 512, ids, coeff)
+    save("cond_N16", seed=np.array([42, 1], dtype=np.uint64), shift=np.array([-0.5]), ids=ids,
+         out=outc.reshape(nb, 512)[ids].copy())
+
     # ---- accessor samples (brick.h:214-327)
     rng = np.random.default_rng(3)
     q = np.stack([rng.integers(0, nb, 512), rng.integers(-8, 16, 512), rng.integers(-8, 16, 512),

@@ -12,8 +12,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-ST_7PT_COEFF, ST_27PT_COEFF, ST_MPI7, ST_MPI13, ST_MPI25, ST_MPI125 = range(6)
-STENCIL_NAMES = {0: "7pt", 1: "27pt", 2: "mpi7", 3: "mpi13", 4: "mpi25", 5: "mpi125"}
+ST_7PT_COEFF, ST_27PT_COEFF, ST_MPI7, ST_MPI13, ST_MPI25, ST_MPI125, ST_COND7 = range(7)
+STENCIL_NAMES = {0: "7pt", 1: "27pt", 2: "mpi7", 3: "mpi13", 4: "mpi25", 5: "mpi125", 6: "cond"}
 
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 _u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
@@ -251,6 +251,8 @@ class Ref:
         L.ref_brick_at.restype = C.c_double
         L.ref_brick_at.argtypes = [_u32p, C.c_uint32, _f64p, C.c_size_t, C.c_uint, C.c_uint32, C.c_int, C.c_int, C.c_int]
         L.ref_brick_taps.argtypes = [_u32p, C.c_uint32, _f64p, _f64p, C.c_size_t, _u32p, C.c_long, _i32p, C.c_int, _f64p]
+        if hasattr(L, 'ref_brick_cond'):
+            L.ref_brick_cond.argtypes = [_u32p, C.c_uint32, _f64p, _f64p, C.c_size_t, _u32p, C.c_long, _f64p]
         L.ref_bitset_of.restype = C.c_uint64
         L.ref_bitset_of.argtypes = [_i32p, C.c_int]
         L.ref_bitset_neg.restype = C.c_uint64
@@ -300,6 +302,11 @@ class Ref:
         coeff = np.ascontiguousarray(coeff, dtype=np.float64)
         self.L.ref_brick_taps(adj.reshape(-1), adj.shape[0], bin_, bout, step, ids, ids.size, taps.reshape(-1),
                               taps.shape[0], coeff)
+
+    def brick_cond(self, adj, bin_, bout, step, ids, coeff):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        coeff = np.ascontiguousarray(coeff, dtype=np.float64)
+        self.L.ref_brick_cond(adj.reshape(-1), adj.shape[0], bin_, bout, step, ids, ids.size, coeff)
 
     def array_stencil(self, name, arr_in, arr_out, lo, hi):
         ext = (arr_in.shape[2], arr_in.shape[1], arr_in.shape[0])

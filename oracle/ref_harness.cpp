@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <algorithm>
 #include <vector>
 
 #include "brick.h"
@@ -115,6 +116,32 @@ void ref_brick_taps(uint32_t *adj, uint32_t nbricks, double *bin, double *bout, 
           for (int t = 1; t < ntaps; ++t)
             acc = acc + coeff[taps[t * 4 + 3]] * bIn[b][k + taps[t * 4]][j + taps[t * 4 + 1]][i + taps[t * 4 + 2]];
           bOut[b][k][j][i] = acc;
+        }
+  }
+}
+
+// d3cond brick form (stencils/3axis.cpp:137-146) through the reference accessor: taps clipped at zero with std::max,
+// 7-pt term order, absolute value of the sum.
+void ref_brick_cond(uint32_t *adj, uint32_t nbricks, double *bin, double *bout, size_t step, const uint32_t *ids, long n,
+                    const double *coeff) {
+  using std::max;
+  BrickInfo<3> bInfo(0);
+  free(bInfo.adj);
+  bInfo.adj = (BrickInfo<3>::adjlist)adj;
+  bInfo.nbricks = nbricks;
+  BrickStorage sti = wrap_storage(bin, nbricks, step);
+  BrickStorage sto = wrap_storage(bout, nbricks, step);
+  Brick3D bIn(&bInfo, sti, 0), bOut(&bInfo, sto, 0);
+  for (long q = 0; q < n; ++q) {
+    unsigned b = ids[q];
+    for (long k = 0; k < 8; ++k)
+      for (long j = 0; j < 8; ++j)
+        for (long i = 0; i < 8; ++i) {
+          bElem partial = coeff[5] * max(bIn[b][k + 1][j][i], 0.0) + coeff[6] * max(bIn[b][k - 1][j][i], 0.0) +
+                          coeff[3] * max(bIn[b][k][j + 1][i], 0.0) + coeff[4] * max(bIn[b][k][j - 1][i], 0.0) +
+                          coeff[1] * max(bIn[b][k][j][i + 1], 0.0) + coeff[2] * max(bIn[b][k][j][i - 1], 0.0) +
+                          coeff[0] * max(bIn[b][k][j][i], 0.0);
+          bOut[b][k][j][i] = partial > 0 ? partial : -partial;
         }
   }
 }

@@ -102,3 +102,4 @@ def test_example_driver_runs():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300).stdout.decode()
     assert "brick() kernel: result match" in out and "brk_stencil_apply_list: result match" in out, out
+    assert "brick() cond kernel: result match" in out, out

@@ -428,3 +428,28 @@ def test_weak_cycle_overlap_streams_single_rank(oracle, dev):
         torch.cuda.synchronize()
         res.append(stA.dat[512 * 1:512 * d.sep_pos[1]].clone())
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_cond_stencil(oracle, golden, dev, variant):
+    """d3cond (single/hip.cpp calls d3condhip): golden fixture from the reference + oracle on a larger case, list and box forms"""
+    from bricklib_amd._lib import lib
+    from oracle.oracle import ST_COND7
+    try:
+        lib.brk_set_variant(6, variant)
+        z = golden("cond_N16")
+        grid, grid_dev, bInfo, arr, st, bIn, ids = single_setup(oracle, dev, 16, 512)
+        st.dat -= 0.5
+        so = bl.BrickStorage.allocate(bInfo.nbricks, 512, dev)
+        coeff = oracle.coeffs(129, 1)
+        bl.apply_stencil("cond", bIn, bl.Brick(bInfo, so, 0), ids=grid_to_device(ids, dev), coeff=coeff)
+        assert np.abs(so.dat.cpu().numpy().reshape(-1, 512)[ids] - z["out"]).max() <= TOL
+        so.dat.zero_()
+        bl.apply_stencil("cond", bIn, bl.Brick(bInfo, so, 0), box=(0, (4, 4, 4), (1, 1, 1), (2, 2, 2)), coeff=coeff)
+        assert np.abs(so.dat.cpu().numpy().reshape(-1, 512)[ids] - z["out"]).max() <= TOL
+        hin = st.dat.cpu().numpy()
+        want = np.zeros_like(hin)
+        oracle.brick_stencil(ST_COND7, bInfo.adj_host, hin, want, 512, ids=ids, coeff=coeff)
+        assert np.abs(so.dat.cpu().numpy() - want).max() <= TOL
+    finally:
+        lib.brk_set_variant(6, 0)
