@@ -21,7 +21,7 @@ __device__ __forceinline__ gcptr sbase(const double *p) {
 }
 
 template <int KIND, int NW>
-__global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : 2)) void k_cube_wg(
+__global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : (NW == 8 ? 2 : 3))) void k_cube_wg(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
     const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
   constexpr int R = CubeTraits<KIND>::R;
@@ -151,13 +151,21 @@ __global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : 2)) void k
 
 } // namespace
 
-int launch_cube_wg(int stencil_id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
+int launch_cube_wg(int stencil_id, int nw, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
-  const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
-  if (stencil_id == BRK_27PT_COEFF)
+  if (stencil_id == BRK_27PT_COEFF) {
+    const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cube_wg<kCube27, 8>), dim3(wgs), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
-  else
+  } else if (nw == 2) {
+    const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_cube_wg<kCube125, 2>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (nw == 4) {
+    const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_cube_wg<kCube125, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else {
+    const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cube_wg<kCube125, 8>), dim3(wgs), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+  }
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

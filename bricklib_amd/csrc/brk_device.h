@@ -32,7 +32,7 @@ int launch_star_wg(int stencil_id, const uint32_t *adj, const double *in, double
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 
 // 27-/125-point kernels with workgroup-shared i-halos (brk_cubewg.hip)
-int launch_cube_wg(int stencil_id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
+int launch_cube_wg(int stencil_id, int nw, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 
 } // namespace brk

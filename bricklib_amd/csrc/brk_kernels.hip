@@ -181,8 +181,8 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   // 27-pt: shared i-halos (0.57 -> 0.54 ms at 512^3).  125-pt is fp64-VALU/LDS bound (1000 FMAs + 300 ds_reads per lane per
   // brick); the 8-wave lockstep version measured slower (1.51 vs 1.23 ms), so it stays on the generic kernel unless
   // variant 2 asks for the shared one.
-  if ((id == BRK_27PT_COEFF && g_variant[id] != 1) || (id == BRK_MPI125 && g_variant[id] == 2))
-    return launch_cube_wg(id, adj, in, out, step, ids, first, n, cf, st);
+  if ((id == BRK_27PT_COEFF && g_variant[id] != 1) || (id == BRK_MPI125 && (g_variant[id] == 2 || g_variant[id] == 4 || g_variant[id] == 8)))
+    return launch_cube_wg(id, id == BRK_MPI125 ? g_variant[id] : 8, adj, in, out, step, ids, first, n, cf, st);
   switch (id) {
   case BRK_7PT_COEFF: hipLaunchKernelGGL(k_star<kStar7Coeff>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_COND7: hipLaunchKernelGGL(k_star<kStarCond7>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;

@@ -161,7 +161,9 @@ __device__ __forceinline__ void star_brick(double *tile, const uint32_t *__restr
 template <int R>
 struct CubeTile {
   static constexpr int T = 8 + 2 * R;
-  static constexpr int P = R == 1 ? 10 : 12; // i pitch in doubles (R=1 conflict-free; R=2 4 of 32 lanes 2-way)
+  static constexpr int P = R == 1 ? 10 : 12; // i pitch in doubles: some lanes of a half-wave collide 2-way (PMC: half of the LDS cycles
+                                             // of the 125-pt kernel are conflict cycles); pitch 24 is conflict-free but halves occupancy
+                                             // and measured slower (1.37 vs 1.07 ms)
   static constexpr int ELEMS = T * T * P;
   __host__ __device__ static constexpr int at(int kk, int jj, int ii) { return (kk * T + jj) * P + ii; }
   static constexpr int NEXTRA = T * T * T - 512 - 6 * 64 * R;
@@ -229,41 +231,68 @@ __host__ __device__ constexpr int cls125(int a, int b, int c) {
 // planes (256 VGPRs + 256 AGPRs + scratch).  rowp: per-lane pointer to tile(plane 0, row j+R, column 0);
 // co[d]: per-lane column offset of tap di = d-2 (own tile, or a sibling's tile 8 columns away); PS/RS: plane/row pitch.
 template <int PS, int RS>
+__device__ __forceinline__ void cube125_load_plane(double (&v)[25], const double *rowp, const int (&co)[5]) {
+#pragma unroll
+  for (int dj = 0; dj < 5; ++dj)
+#pragma unroll
+    for (int d = 0; d < 5; ++d) v[dj * 5 + d] = rowp[(dj - 2) * RS + co[d]];
+}
+
+// fold one plane (25 values, [dj][di]) and add its contributions to the ring of partial outputs
+__device__ __forceinline__ void cube125_plane(const double (&v)[25], double (&ring)[5], int kk, const Coeffs &cf) {
+  double u[3][3];
+#pragma unroll
+  for (int dj = 0; dj < 5; ++dj) {
+    const double s0 = v[dj * 5 + 2], s1 = v[dj * 5 + 1] + v[dj * 5 + 3], s2 = v[dj * 5] + v[dj * 5 + 4];
+    const int bcls = dj < 2 ? 2 - dj : dj - 2;
+    if (dj <= 2) { // first visit of this |dj| class
+      u[0][bcls] = s0;
+      u[1][bcls] = s1;
+      u[2][bcls] = s2;
+    } else {
+      u[0][bcls] += s0;
+      u[1][bcls] += s1;
+      u[2][bcls] += s2;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    if ((unsigned)(kk - 4 + m) < 8u) { // wave-uniform: the output exists
+      const int c = m < 2 ? 2 - m : m - 2; // |dk|
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) ring[m] += cf.c[cls125(c, bb, a)] * u[a][bb];
+    }
+  }
+}
+
+__device__ __forceinline__ void cube125_retire(double (&ring)[5], int kk, double *dst, int lane) {
+  if (kk >= 4) dst[(kk - 4) * 64 + lane] = ring[0]; // output kk-4 has received its last plane
+#pragma unroll
+  for (int m = 0; m < 4; ++m) ring[m] = ring[m + 1];
+  ring[4] = 0.0;
+}
+
+// Plane loop, software-pipelined by hand: the 25 LDS reads of plane kk+1 are issued before plane kk is folded, with two
+// named value sets (no copies); 6 trips x 2 planes.
+template <int PS, int RS>
 __device__ __forceinline__ void cube125_accumulate(const double *rowp, const int (&co)[5], const Coeffs &cf,
                                                    double *dst, int lane) {
   double ring[5] = {0.0, 0.0, 0.0, 0.0, 0.0}; // ring[m] = partial output k = kk-4+m
+  double va[25], vb[25];
+  cube125_load_plane<PS, RS>(va, rowp, co);
 #pragma unroll 1
-  for (int kk = 0; kk < 12; ++kk, rowp += PS) {
-    double u[3][3];
-#pragma unroll
-    for (int dj = -2; dj <= 2; ++dj) {
-      const double *r = rowp + dj * RS;
-      const double s0 = r[co[2]], s1 = r[co[1]] + r[co[3]], s2 = r[co[0]] + r[co[4]];
-      const int bcls = dj < 0 ? -dj : dj;
-      if (dj <= 0) { // first visit of this |dj| class
-        u[0][bcls] = s0;
-        u[1][bcls] = s1;
-        u[2][bcls] = s2;
-      } else {
-        u[0][bcls] += s0;
-        u[1][bcls] += s1;
-        u[2][bcls] += s2;
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < 5; ++m) {
-      if ((unsigned)(kk - 4 + m) < 8u) { // wave-uniform: the output exists
-        const int c = m < 2 ? 2 - m : m - 2; // |dk|
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int bb = 0; bb < 3; ++bb) ring[m] += cf.c[cls125(c, bb, a)] * u[a][bb];
-      }
-    }
-    if (kk >= 4) dst[(kk - 4) * 64 + lane] = ring[0]; // output kk-4 has received its last plane
-#pragma unroll
-    for (int m = 0; m < 4; ++m) ring[m] = ring[m + 1];
-    ring[4] = 0.0;
+  for (int kk = 0; kk < 12; kk += 2) {
+    cube125_load_plane<PS, RS>(vb, rowp + PS, co);
+    __builtin_amdgcn_sched_barrier(0); // keep the reads of the next plane ahead of this plane's arithmetic
+    cube125_plane(va, ring, kk, cf);
+    cube125_retire(ring, kk, dst, lane);
+    if (kk + 2 < 12) cube125_load_plane<PS, RS>(va, rowp + 2 * PS, co);
+    __builtin_amdgcn_sched_barrier(0);
+    cube125_plane(vb, ring, kk + 1, cf);
+    cube125_retire(ring, kk + 1, dst, lane);
+    rowp += 2 * PS;
   }
 }
 
