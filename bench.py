@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--workload", default=None, choices=[None, "single", "weak"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--schedule", default="auto", choices=("auto", "deep", "surface", "plain"),
+                    help="weak workload: deep = exchange hidden behind the early passes of all sweeps, surface = behind "
+                         "the inner bricks of one sweep, plain = in order, auto = pick deep/surface from the measured exchange time")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -162,18 +165,45 @@ def run_weak(args, bl, dev, rank, world):
     stA.dat.uniform_(0.0, 1.0)
     A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
     ex = Exchanger(d, stA, rank)
-    from bricklib_amd.drivers import SweepLists
-    lists = SweepLists(d, dev)
+    from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
+    S = bl.stencil_iters(sid)
     main = torch.cuda.current_stream()
     comm = torch.cuda.Stream()
-    overlap = not args.no_overlap
-
+    schedule = "plain" if args.no_overlap else args.schedule
+    probe_ms = None
+    if schedule == "auto":
+        # measure, don't guess: the exchange alone, max over ranks.  "surface" hides it behind the inner bricks of one
+        # sweep on either side (~0.7 ms of compute at 512^3) at no cost; "deep" hides it behind the early passes of all
+        # sweeps (~2 ms) for ~4 % more compute time (thicker shells, more launches).
+        t0_, t1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(7):
+            if it == 2:
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t0_.record(main)
+            ex.exchange(main)
+        t1_.record(main)
+        torch.cuda.synchronize()
+        x = torch.tensor([t0_.elapsed_time(t1_) / 5], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        probe_ms = float(x.item())
+        inner_ms = BYTES_PER_UPDATE * float(N - 16) ** 3 / (HBM_COPY_GBS * 1e9 * 0.8) * 1e3
+        schedule = "deep" if probe_ms > 1.5 * inner_ms else "surface"
+    overlap = schedule != "plain"
     state = {}
+    if schedule == "deep":
+        lists = TrapezoidLists(d, S, dev)
 
-    def step():
-        return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=comm, overlap=overlap, lists=lists, state=state)
+        def step():
+            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=comm)
+    else:
+        lists = SweepLists(d, dev)
 
-    S = bl.stencil_iters(sid)
+        def step():
+            return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=comm, overlap=overlap, lists=lists, state=state)
+
     for _ in range(W):
         step()
     torch.cuda.synchronize()
@@ -195,11 +225,21 @@ def run_weak(args, bl, dev, rank, world):
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    # outside the timed region: the exchange alone (device links + RCCL), for reading the scaling numbers
+    xs, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    xs.record(main)
+    for _ in range(5):
+        ex.exchange(main)
+    x1.record(main)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    exchange_ms = xs.elapsed_time(x1) / 5
     cells = float(N) ** 3 * S * world
     res = {"workload": f"weak-{name}-{N}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,
-           "kernel": "k_star<%s> over brick ranges of BrickDecomp(%d^3): %d sweeps + 1 exchange per step" % (name, N, S),
-           "cart": cart, "overlap": overlap, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
+           "kernel": "%s sweeps over brick lists of BrickDecomp(%d^3): %d sweeps + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S),
+           "cart": cart, "overlap": overlap, "schedule": schedule, "schedule_probe_ms": probe_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
            "remote_bytes_per_rank": ex.bytes_remote}
     return res, {}
 
@@ -232,12 +272,12 @@ def main():
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": args.n ** 3,
-                       **{k: res[k] for k in ("cart", "overlap", "exchange_bytes_per_rank", "remote_bytes_per_rank") if k in res}},
+                       **{k: res[k] for k in ("cart", "overlap", "schedule", "schedule_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank", "remote_bytes_per_rank") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],
                          "kernel_ms": res["kernel_ms"], "algorithmic_bytes_per_launch": res["alg_bytes_per_launch"]},
         }
-        # HBM-side traffic per launch from the committed PMC passes of this same command (prof_pmc.sh); null when the
+        # HBM-side traffic per launch from the committed PMC passes of this same command (tools/prof_pmc.sh); null when the
         # stored measurement is for another workload
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))

@@ -10,7 +10,7 @@ the region ordering of BrickDecomp the three brick sets involved are plain id ra
 import torch
 
 from .brick import grid_to_device
-from .order import decomp_lists
+from .order import decomp_lists, trapezoid_lists
 from .stencils import apply_stencil, stencil_iters
 
 
@@ -68,4 +68,44 @@ def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, ove
         sweep(B, A, "inner")             # ... is ready before the bulk of the last sweep
     else:
         sweep(B, A, "domain")
+    return S
+
+
+class TrapezoidLists:
+    """Device-resident lists of bricklib_amd.order.trapezoid_lists for `sweeps` sweeps per exchange."""
+
+    def __init__(self, d, sweeps, device, rows_per_block=8):
+        inner, shell = trapezoid_lists(d, sweeps, rows_per_block)
+        self.inner = [grid_to_device(x, device) if x.size else None for x in inner]
+        self.shell = [grid_to_device(x, device) if x.size else None for x in shell]
+
+
+def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, comm=None):
+    """Same result as weak_cycle, scheduled so that the exchange hides behind most of the cycle instead of one sweep
+    (xGMI is a per-link-bound point-to-point fabric; a 512^3 subdomain sends 104 MB per exchange).  While the ghosts
+    of A travel on `comm`, `main` runs the part of EVERY sweep that cannot depend on them yet -- sweep t over the bricks
+    at least t+1 bricks inside the ghosted grid (a shrinking box, 59 % of all brick updates at 512^3 / 8 sweeps) -- and
+    afterwards the remaining shells of sweeps 1..S in order.  Ping-pong safety: the early pass of sweep t+2 overwrites
+    the source of sweep t+1 only at depth >= t+3, while the late pass of sweep t+1 reads depth <= t+2.
+    lists: TrapezoidLists(d, stencil_iters(stencil))."""
+    S = stencil_iters(stencil)
+    assert len(lists.inner) == S
+    main = main or torch.cuda.current_stream()
+    if comm is None:
+        exchange(main)
+    else:
+        ev0 = torch.cuda.Event()
+        ev0.record(main)                 # A as left by the previous cycle
+        comm.wait_event(ev0)
+        exchange(comm)
+        ev1 = torch.cuda.Event()
+        ev1.record(comm)
+    for ids in (lists.inner, lists.shell):
+        src, dst = A, B
+        for t in range(S):
+            if ids[t] is not None:
+                apply_stencil(stencil, src, dst, ids=ids[t], coeff=coeff, stream=main)
+            src, dst = dst, src
+        if comm is not None and ids is lists.inner:
+            main.wait_event(ev1)
     return S

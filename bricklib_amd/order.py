@@ -72,3 +72,39 @@ def decomp_lists(d, rows_per_block=8):
     return {"inner": assemble(inner_s), "shell": shell, "surface": surface,
             "all": assemble(inner_s, chunks(shell)),          # [1,sep2): subdomain + ghost ring
             "domain": assemble(inner_s, chunks(surface))}     # [1,sep1): the subdomain itself
+
+
+def _box(grid, lo, hi):
+    return grid[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
+
+
+def trapezoid_lists(d, sweeps, rows_per_block=8):
+    """Brick lists for the deep-overlap schedule of drivers.weak_cycle_deep.  With L(b) = distance of brick b from the
+    outside of the ghosted grid in bricks (ghost ring: 0, surface: 1, ...), sweep t = 1..sweeps is split into
+        inner[t-1] -- bricks with L >= t+1: they depend on nothing the exchange delivers (the dependence cone of the
+                      ghost ring widens by at most one brick per sweep, radius*sweeps <= 8 cells), and
+        shell[t-1] -- bricks with L <= t (the last sweep leaves out the ghost ring, `skip = 1` of weak/main.cpp:198-207).
+    inner + shell is exactly the brick set the reference computes in sweep t.  Returns (inner, shell): two lists of
+    uint32 arrays (possibly empty)."""
+    g = np.asarray(d.grid).astype(np.uint32)
+    T = [g.shape[2], g.shape[1], g.shape[0]]          # bricks per axis (i,j,k) incl. ghost
+    inner, shell = [], []
+    for t in range(1, sweeps + 1):
+        lo = [1 if t == sweeps else 0] * 3            # outer box [lo, T-lo)
+        hi = [T[a] - lo[a] for a in range(3)]
+        ilo = [t + 1] * 3
+        ihi = [T[a] - t - 1 for a in range(3)]
+        if any(ihi[a] <= ilo[a] for a in range(3)):   # the cone has closed: everything waits for the exchange
+            inner.append(np.zeros(0, dtype=np.uint32))
+            shell.append(tiled(_box(g, lo, hi), rows_per_block))
+            continue
+        inner.append(tiled(_box(g, ilo, ihi), rows_per_block))
+        klo = slabs(_box(g, lo, [hi[0], hi[1], ilo[2]]), rows_per_block)
+        khi = slabs(_box(g, [lo[0], lo[1], ihi[2]], hi), rows_per_block)
+        rest = [_box(g, [lo[0], lo[1], ilo[2]], [hi[0], ilo[1], ihi[2]]),        # j-low / j-high
+                _box(g, [lo[0], ihi[1], ilo[2]], [hi[0], hi[1], ihi[2]]),
+                _box(g, [lo[0], ilo[1], ilo[2]], [ilo[0], ihi[1], ihi[2]]),      # i-low / i-high
+                _box(g, [ihi[0], ilo[1], ilo[2]], [hi[0], ihi[1], ihi[2]])]
+        rest = np.concatenate([np.ascontiguousarray(r).reshape(-1) for r in rest])
+        shell.append(assemble(klo, khi, chunks(rest)))
+    return inner, shell

@@ -158,7 +158,17 @@ def test_link_copy(dev):
 def test_weak_cycle_virtual_ranks(oracle, dev, name, nranks):
     """weak/main.cpp brick_func with `nranks` ranks of a periodic cart grid living on ONE GPU (device links as the
     transport).  Oracle: the same global periodic field swept ST_ITER times as one array."""
-    dom = (16, 16, 16)
+    _weak_virtual(oracle, dev, name, nranks, (16, 16, 16), "lists" if nranks != 2 else "ranges")
+
+
+@pytest.mark.parametrize("name,nranks", [("mpi7pt", 2), ("mpi7pt", 8), ("mpi13pt", 4), ("mpi25pt", 1)])
+def test_weak_cycle_deep_schedule_virtual_ranks(oracle, dev, name, nranks):
+    """the deep-overlap schedule (drivers.weak_cycle_deep: early shrinking-box passes of every sweep, then the shells)
+    against the global periodic field, on subdomains large enough that the early passes are not empty"""
+    _weak_virtual(oracle, dev, name, nranks, (40, 32, 48), "deep")
+
+
+def _weak_virtual(oracle, dev, name, nranks, dom, schedule):
     cart = bl.dims_create(nranks)
     gdims = [cart[2 - a] * dom[a] for a in range(3)]
     seed = 11
@@ -180,12 +190,18 @@ def test_weak_cycle_virtual_ranks(oracle, dev, name, nranks):
     table = LinkTable(links, dev)
     S = bl.stencil_iters(name)
     ncycles = 2
-    from bricklib_amd.drivers import SweepLists
-    lists = SweepLists(d, dev) if nranks != 2 else None      # both the list and the plain-range schedules
+    from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
+    lists = {"lists": lambda: SweepLists(d, dev), "ranges": lambda: None, "deep": lambda: TrapezoidLists(d, S, dev)}[schedule]()
+    if schedule == "deep":
+        assert lists.inner[0] is not None
     for _ in range(ncycles):
         table.run()                     # every rank's exchange
         for r in range(nranks):
-            weak_cycle(name, d, bl.Brick(info, stA[r], 0), bl.Brick(info, stB[r], 0), lambda s: None, lists=lists)
+            A, B = bl.Brick(info, stA[r], 0), bl.Brick(info, stB[r], 0)
+            if schedule == "deep":
+                weak_cycle_deep(name, d, A, B, lambda s: None, lists)
+            else:
+                weak_cycle(name, d, A, B, lambda s: None, lists=lists)
     torch.cuda.synchronize()
     # oracle: global periodic field, wrap-padded by 8 cells, S sweeps per cycle
     gext = tuple(g + 16 for g in gdims)
@@ -406,28 +422,30 @@ def test_weak_cycle_overlap_streams_single_rank(oracle, dev):
     """The overlapped schedule (exchange on a second stream, surface-first last sweep, event hand-over between cycles)
     gives the same field as the plain in-order schedule."""
     from bricklib_amd.decomp import Exchanger
-    from bricklib_amd.drivers import SweepLists
+    from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
     dom = (64, 48, 56)
     d = bl.BrickDecomp(dom)
     bl.populate(d, [1, 1, 1], [0, 0, 0])
     info = d.getBrickInfo(dev)
     res = []
-    for mode in ("plain", "overlap"):
+    for mode in ("plain", "overlap", "deep"):
         torch.manual_seed(3)
         stA, stB = info.allocate(512, dev), info.allocate(512, dev)
         stA.dat.uniform_(0.0, 1.0)
         A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
         ex = Exchanger(d, stA, 0)
-        lists = SweepLists(d, dev)
+        lists, deep = SweepLists(d, dev), TrapezoidLists(d, 8, dev)
         main, comm, state = torch.cuda.current_stream(), torch.cuda.Stream(), {}
         for _ in range(3):
             if mode == "plain":
                 weak_cycle("mpi7pt", d, A, B, ex.exchange, lists=lists)
+            elif mode == "deep":
+                weak_cycle_deep("mpi7pt", d, A, B, ex.exchange, deep, main=main, comm=comm)
             else:
                 weak_cycle("mpi7pt", d, A, B, ex.exchange, main=main, comm=comm, overlap=True, lists=lists, state=state)
         torch.cuda.synchronize()
         res.append(stA.dat[512 * 1:512 * d.sep_pos[1]].clone())
-    assert torch.equal(res[0], res[1])
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2])

@@ -117,3 +117,56 @@ def test_exchange_plan_covers_ghost_once():
     assert (covered[d.sep_pos[1]:d.sep_pos[2]] == 1).all() and covered[:d.sep_pos[1]].sum() == 0
     for s in d.skin:
         assert d.sep_pos[0] <= s["pos"] and s["pos"] + s["len"] <= d.sep_pos[1]
+
+
+@pytest.mark.parametrize("dom,sweeps", [((64, 48, 56), 8), ((40, 32, 48), 4), ((16, 16, 16), 2), ((96, 96, 96), 8)])
+def test_deep_schedule_dataflow(dom, sweeps):
+    """drivers.weak_cycle_deep replayed on version stamps: every pass of sweep t reads only sweep t-1 data, the early
+    passes touch nothing the exchange reads or writes, and each sweep covers exactly the reference's brick set
+    (weak/main.cpp:186-207: all bricks incl. ghost, the last sweep without the ghost ring)."""
+    from bricklib_amd.order import LIST_SKIP, trapezoid_lists
+    d = bl.BrickDecomp(dom)
+    inner, shell = trapezoid_lists(d, sweeps)
+    sep0, sep1, sep2 = d.sep_pos
+    nb = d.nbricks
+    GARBAGE = -100
+    ver = {"A": np.zeros(nb, dtype=np.int64), "B": np.full(nb, GARBAGE, dtype=np.int64)}
+    ver["A"][sep1:sep2] = GARBAGE            # ghosts of A are stale until the exchange lands
+    adj = d.adj
+    # L(b): bricks from the outside of the ghosted grid
+    T = d.grid.shape
+    kk, jj, ii = np.meshgrid(*[np.minimum(np.arange(n), n - 1 - np.arange(n)) for n in T], indexing="ij")
+    L = np.zeros(nb, dtype=np.int64)
+    L[d.grid.reshape(-1)] = np.minimum(np.minimum(kk, jj), ii).reshape(-1)
+
+    def run(ids, t, early):
+        src, dst = ("A", "B") if t % 2 == 1 else ("B", "A")
+        ids = ids[ids != LIST_SKIP].astype(np.int64)
+        if ids.size == 0:
+            return ids
+        nbrs = adj[ids]                                           # [n][27]; 0 = outside the ghosted grid
+        need = ver[src][nbrs]
+        if early:
+            assert (L[ids] >= t + 1).all()
+            assert (need == t - 1).all()                          # nothing stale, nothing from a later sweep
+            if src == "A":
+                assert (L[nbrs] >= 1).all() and (nbrs != 0).all()  # never reads a ghost brick the exchange is writing
+            if dst == "A":
+                assert (L[ids] >= 2).all()                        # never writes what the exchange is sending
+        else:
+            # late passes: everything a DOMAIN brick will ever depend on is current; stale data may only enter
+            # through the outside of the ghosted grid (brick 0), as in the reference
+            assert ((need == t - 1) | (nbrs == 0)).all()
+        ver[dst][ids] = t
+        return ids
+
+    for t in range(1, sweeps + 1):
+        run(inner[t - 1], t, True)
+    ver["A"][np.where(ver["A"][sep1:sep2] == GARBAGE)[0] + sep1] = 0      # exchange complete: A's ghosts are sweep-0 data
+    assert (ver["A"][sep1:sep2] == 0).all()
+    for t in range(1, sweeps + 1):
+        early_ids = inner[t - 1][inner[t - 1] != LIST_SKIP]
+        late_ids = run(shell[t - 1], t, False)
+        both = np.sort(np.concatenate([early_ids.astype(np.int64), late_ids]))
+        assert np.array_equal(both, np.arange(1, sep1 if t == sweeps else sep2))
+    assert sweeps % 2 == 0 and (ver["A"][1:sep1] == sweeps).all()
