@@ -146,7 +146,7 @@ __global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : (NW == 8 ?
       }
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) dst[k * 64 + lane] = acc[k];
+  for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
 }
 
 } // namespace

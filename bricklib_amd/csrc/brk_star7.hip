@@ -124,7 +124,7 @@ __device__ __forceinline__ void compute_store(const double *tile, const Faces &f
     const double kp = k == 7 ? f.kp : f.own[k < 7 ? k + 1 : 7];
     double res;
     res = point7<MPI>(kp, km, jp, jm, ip, im, c0, cf);
-    dst[k * 64 + lane] = res;
+    store_result(&dst[k * 64 + lane], res);
   }
 }
 
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
     const double kp = k == 7 ? f.kp : f.own[k < 7 ? k + 1 : 7];
     double res;
     res = point7<MPI>(kp, km, jp, jm, ip, im, c0, cf);
-    dst[k * 64 + lane] = res;
+    store_result(&dst[k * 64 + lane], res);
   }
 }
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * NW, (StarTraits<KIND>::R == 4 ? 3 : 4)) void k
       res = (r == R) ? sh * cf.c[r] : res + sh * cf.c[r];
     }
     res = res + col[R + k] * cf.c[0];
-    dst[k * 64 + lane] = res;
+    store_result(&dst[k * 64 + lane], res);
   }
 }
 

@@ -23,6 +23,14 @@ struct Coeffs {
 // adjacency slot of direction (dk,dj,di), include/brick.h:237-245 of the reference
 __host__ __device__ constexpr int adj_slot(int dk, int dj, int di) { return (dk + 1) * 9 + (dj + 1) * 3 + (di + 1); }
 
+// Results leave the chip with the non-temporal hint (`global_store ... nt`): a sweep never re-reads what it writes, so
+// the output stream should not displace the input bricks whose faces the following rows and planes still need from L2.
+// Measured on the 512^3 7-point sweep: 0.402 -> 0.379 ms (profiles/).
+template <class P>
+__device__ __forceinline__ void store_result(P *p, double v) {
+  __builtin_nontemporal_store(v, p);
+}
+
 // Wave-local LDS ordering.  The hardware runs one wave's DS instructions in order; these only stop the
 // compiler from moving a lane's reads above other lanes' writes.
 __device__ __forceinline__ void wave_lds_sync() {
@@ -149,7 +157,7 @@ __device__ __forceinline__ void star_brick(double *tile, const uint32_t *__restr
       }
       res = res + c0 * cf.c[0];
     }
-    dst[k * 64 + lane] = res;
+    store_result(&dst[k * 64 + lane], res);
   }
 }
 
@@ -268,7 +276,7 @@ __device__ __forceinline__ void cube125_plane(const double (&v)[25], double (&ri
 }
 
 __device__ __forceinline__ void cube125_retire(double (&ring)[5], int kk, double *dst, int lane) {
-  if (kk >= 4) dst[(kk - 4) * 64 + lane] = ring[0]; // output kk-4 has received its last plane
+  if (kk >= 4) store_result(&dst[(kk - 4) * 64 + lane], ring[0]); // output kk-4 has received its last plane
 #pragma unroll
   for (int m = 0; m < 4; ++m) ring[m] = ring[m + 1];
   ring[4] = 0.0;
@@ -380,7 +388,7 @@ __device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restr
   }
   double *dst = out + (size_t)b * step;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) dst[k * 64 + lane] = acc[k];
+  for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
 }
 
 
