@@ -1,0 +1,284 @@
+// brk_cubedense.hip -- cube stencils (27- and 125-point) on dense, bank-conflict-free LDS tiles.
+//
+// The padded (8+2R)^3 tile of brk_cubewg.hip has a row pitch of 10/12 doubles: every ds_read_b64 of the accumulation
+// loop is 2-way bank conflicted (a 32-lane half touches rows 4 pitches apart; measured: 50 % of the LDS cycles of the
+// 125-point kernel are conflict cycles, profiles/r01_c_pmc_mpi125pt_512.txt) and the tile costs 8 / 13.8 KiB per wave.
+//
+// Here a wave's tile holds only the 8 interior columns of every (k,j) row of the halo'd brick: D[T][T][8], T = 8+2R,
+// row pitch 8 doubles = 64 B.  Lane (j,i) of a 32-lane half reads row (j+dj), column (i+di) mod 8: 4 rows x 8 columns
+// = 32 different banks for every tap.  The columns a tap needs beyond the brick (i+di < 0 or > 7) live, at the SAME row
+// offset, in the tile of the i-neighbour -- the previous / next wave of the workgroup when the brick list runs along i
+// (the usual case; tile pitch is a multiple of 32 doubles, so the bank pattern is unchanged).  A wave without such a
+// sibling (first/last of the group, list padding, irregular lists) gathers its i-halo itself and parks it in the
+// columns 8-R..7 / 0..R-1 of the slot on that side: slot F in front of tile 0 (shared by the group's two ends), or the
+// slot of a wave that is idle.  Two ACTIVE neighbours that are not i-neighbours would need each other's slot, so the
+// runs of a group are 2-coloured and processed in two phases; regular lists never take the second phase.
+// Links are exact: a pair shares only if all 9 adjacency entries on the common side agree both ways, so any BrickInfo
+// is handled (irregular ones at fallback speed).
+// LDS per workgroup: (NW+1) tiles = 57.6 KiB (27-pt, NW 8, 2 groups/CU) / 46 KiB (125-pt, NW 4, 3 groups/CU).
+#include "brk_device.h"
+
+namespace brk {
+namespace {
+
+typedef const __attribute__((address_space(1))) double *gcptr;
+typedef __attribute__((address_space(1))) double *gptr;
+__device__ __forceinline__ gcptr sbase(const double *p) {
+  gcptr g = (gcptr)p;
+  asm volatile("" : "+s"(g)); // SGPR base + 32-bit lane offset addressing (see brk_star7.hip)
+  return g;
+}
+
+template <int R>
+struct DenseTile {
+  static constexpr int T = 8 + 2 * R;
+  static constexpr int ELEMS = T * T * 8;
+  static_assert(ELEMS % 32 == 0, "sibling tiles must keep the bank pattern");
+  __host__ __device__ static constexpr int at(int kk, int jj, int c) { return (kk * T + jj) * 8 + c; }
+  // edge/corner cells of the halo, grouped by the side they are staged on (each group padded to whole 64-lane gathers)
+  static constexpr int N0 = 4 * R * R * 8;              // di = 0: the four k-j edges
+  static constexpr int NS = (T * T - 64) * R;           // di = -1 (or +1): every (k,j) row outside the i-face itself
+  static constexpr int IT0 = (N0 + 63) / 64, ITS = (NS + 63) / 64;
+  static constexpr int EXTRA_ITERS = IT0 + 2 * ITS;
+};
+
+// One descriptor per cell:
+//   offset inside the destination slot | adjacency slot << 16 | element offset inside the source brick << 21
+// Group 0 (di = 0) goes into the wave's own tile, group 1 (di = -1) into columns 8-R..7 of the slot on the left, group 2
+// (di = +1) into columns 0..R-1 of the slot on the right; a wave whose i-neighbour is a sibling skips that group entirely.
+template <int R>
+struct DenseExtra {
+  uint32_t e[DenseTile<R>::EXTRA_ITERS * 64];
+};
+
+template <int R>
+constexpr DenseExtra<R> make_dense_extra() {
+  DenseExtra<R> t{};
+  using TL = DenseTile<R>;
+  constexpr int T = 8 + 2 * R;
+  for (int q = 0; q < TL::EXTRA_ITERS * 64; ++q) t.e[q] = 0xFFFFFFFFu;
+  for (int side = 0; side < 3; ++side) {
+    int n = (side == 0 ? 0 : (side == 1 ? TL::IT0 : TL::IT0 + TL::ITS)) * 64;
+    for (int kk = 0; kk < T; ++kk)
+      for (int jj = 0; jj < T; ++jj)
+        for (int ii = 0; ii < T; ++ii) {
+          const int dk = kk < R ? -1 : (kk >= R + 8 ? 1 : 0);
+          const int dj = jj < R ? -1 : (jj >= R + 8 ? 1 : 0);
+          const int di = ii < R ? -1 : (ii >= R + 8 ? 1 : 0);
+          if ((dk != 0) + (dj != 0) + (di != 0) < 2) continue;
+          if ((di < 0 ? 1 : (di > 0 ? 2 : 0)) != side) continue;
+          const int sk = (kk - R + 8) % 8, sj = (jj - R + 8) % 8, si = (ii - R + 8) % 8;
+          const int col = di < 0 ? 8 - R + ii : (di > 0 ? ii - R - 8 : ii - R);
+          t.e[n++] = (uint32_t)TL::at(kk, jj, col) | ((uint32_t)adj_slot(dk, dj, di) << 16) |
+                     ((uint32_t)(sk * 64 + sj * 8 + si) << 21);
+        }
+  }
+  return t;
+}
+
+__device__ const DenseExtra<1> g_dense1 = make_dense_extra<1>();
+__device__ const DenseExtra<2> g_dense2 = make_dense_extra<2>();
+template <int R>
+__device__ __forceinline__ const uint32_t *dense_table() {
+  if (R == 1) return g_dense1.e;
+  return g_dense2.e;
+}
+
+// Do bricks `left` and `right` (adjacency rows in lanes 0..26 of rl / rr) see the same world across their common i-face?
+// right(dk,dj,-1) == left(dk,dj,0) and right(dk,dj,0) == left(dk,dj,+1) for all 9 (dk,dj) -- this includes right.im == left
+// and left.ip == right; entry (dk,dj,di) sits in lane (dk+1)*9+(dj+1)*3+(di+1).
+__device__ __forceinline__ bool linked(uint32_t rl, uint32_t rr, int lane) {
+  // left is one brick to the left of right, so left's entry in column di+1 must be right's entry in column di
+  const uint32_t l_up = (uint32_t)__shfl((int)rl, lane + 1);
+  const bool ok = !(lane < 27 && lane % 3 != 2) || rr == l_up;
+  return __ballot(!ok) == 0ull;
+}
+
+template <int KIND, int NW, int OCC, bool PIPE = true>
+__global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
+    const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
+    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
+  constexpr int R = CubeTraits<KIND>::R;
+  using TL = DenseTile<R>;
+  constexpr int E = TL::ELEMS;
+  __shared__ double lds[(NW + 1) * E];
+  __shared__ uint32_t breaks[NW];
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t slot = wg * NW + w;
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 3, lo = lane & 7;
+  double *tile = lds + (w + 1) * E;                         // slot 0 is F, tile v is slot v+1
+  double *left = tile - E;                                  // tile w-1, or F for w = 0
+  const int roff = w == NW - 1 ? -NW * E : E;               // tile w+1, or F for the last wave
+  double *right = tile + roff;
+  auto id_of = [&](uint32_t sl) -> uint32_t { return ids ? ids[sl] : first + sl; };
+
+  const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;
+  const bool active = b != BRK_LIST_SKIP;
+  bool link_l = false, link_r = false, brk_l = false;
+  double own[8], fkm[R], fkp[R], fjm[R], fjp[R], fim[R], fip[R];
+  double xv[TL::EXTRA_ITERS];
+  uint32_t xd[TL::EXTRA_ITERS];
+  if (active) {
+    const uint32_t b_prev = w > 0 ? __builtin_amdgcn_readfirstlane(id_of(slot - 1)) : BRK_LIST_SKIP;
+    const uint32_t b_next = (w + 1 < NW && slot + 1 < n) ? __builtin_amdgcn_readfirstlane(id_of(slot + 1)) : BRK_LIST_SKIP;
+    const int l27 = lane < 27 ? lane : 13;
+    const uint32_t arow = adj[(size_t)b * 27 + l27]; // lanes 0..26: the adjacency row
+    const gcptr self = sbase(in + (size_t)b * step);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) own[k] = self[k * 64 + lane];
+    const uint32_t prow = adj[(size_t)(b_prev != BRK_LIST_SKIP ? b_prev : b) * 27 + l27];
+    const uint32_t nrow = adj[(size_t)(b_next != BRK_LIST_SKIP ? b_next : b) * 27 + l27];
+    link_l = b_prev != BRK_LIST_SKIP && linked(prow, arow, lane);
+    link_r = b_next != BRK_LIST_SKIP && linked(arow, nrow, lane);
+    brk_l = b_prev != BRK_LIST_SKIP && !link_l; // two active neighbours that cannot share
+    const uint32_t n_im = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, -1));
+    const uint32_t n_ip = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, 1));
+    const gcptr p_km = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(-1, 0, 0)) * step);
+    const gcptr p_kp = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(1, 0, 0)) * step);
+    const gcptr p_jm = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, -1, 0)) * step);
+    const gcptr p_jp = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 1, 0)) * step);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      fkm[r] = p_km[(8 - R + r) * 64 + lane];
+      fkp[r] = p_kp[r * 64 + lane];
+      fjm[r] = p_jm[hi * 64 + (8 - R + r) * 8 + lo];
+      fjp[r] = p_jp[hi * 64 + r * 8 + lo];
+      fim[r] = fip[r] = 0.0;
+    }
+    if (!link_l) {
+      const gcptr p_im = sbase(in + (size_t)n_im * step);
+#pragma unroll
+      for (int r = 0; r < R; ++r) fim[r] = p_im[hi * 64 + lo * 8 + (8 - R + r)];
+    }
+    if (!link_r) {
+      const gcptr p_ip = sbase(in + (size_t)n_ip * step);
+#pragma unroll
+      for (int r = 0; r < R; ++r) fip[r] = p_ip[hi * 64 + lo * 8 + r];
+    }
+    const uint32_t *xt = dense_table<R>();
+    auto gather = [&](int t) {
+      xd[t] = xt[t * 64 + lane];
+      const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((xd[t] >> 16) & 31u) << 2), (int)arow);
+      xv[t] = xd[t] != 0xFFFFFFFFu ? in[(size_t)nb * step + ((xd[t] >> 21) & 511u)] : 0.0;
+    };
+#pragma unroll
+    for (int t = 0; t < TL::IT0; ++t) gather(t);
+    if (!link_l) {
+#pragma unroll
+      for (int t = TL::IT0; t < TL::IT0 + TL::ITS; ++t) gather(t);
+    }
+    if (!link_r) {
+#pragma unroll
+      for (int t = TL::IT0 + TL::ITS; t < TL::EXTRA_ITERS; ++t) gather(t);
+    }
+  }
+  if (lane == 0) breaks[w] = brk_l ? 1u : 0u;
+  __syncthreads();
+  // 2-colouring of the runs: phase of wave w = parity of the breaks at or before it
+  const unsigned long long bm = __ballot(lane < NW && breaks[lane < NW ? lane : 0] != 0u);
+  const int my_phase = __builtin_popcountll(bm & ((2ull << w) - 1ull)) & 1;
+  const int nphase = bm ? 2 : 1;
+
+  gptr dst = (gptr)(out + (size_t)(active ? b : 0) * step);
+  asm volatile("" : "+s"(dst));
+  for (int ph = 0; ph < nphase; ++ph) {
+    const bool mine = active && my_phase == ph;
+    if (mine) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) tile[TL::at(k + R, hi + R, lo)] = own[k];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        tile[TL::at(r, hi + R, lo)] = fkm[r];
+        tile[TL::at(R + 8 + r, hi + R, lo)] = fkp[r];
+        tile[TL::at(hi + R, r, lo)] = fjm[r];
+        tile[TL::at(hi + R, R + 8 + r, lo)] = fjp[r];
+      }
+      if (!link_l) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) left[TL::at(hi + R, lo + R, 8 - R + r)] = fim[r];
+      }
+      if (!link_r) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) right[TL::at(hi + R, lo + R, r)] = fip[r];
+      }
+#pragma unroll
+      for (int t = 0; t < TL::IT0; ++t)
+        if (xd[t] != 0xFFFFFFFFu) tile[xd[t] & 0xFFFFu] = xv[t];
+      if (!link_l) {
+#pragma unroll
+        for (int t = TL::IT0; t < TL::IT0 + TL::ITS; ++t)
+          if (xd[t] != 0xFFFFFFFFu) left[xd[t] & 0xFFFFu] = xv[t];
+      }
+      if (!link_r) {
+#pragma unroll
+        for (int t = TL::IT0 + TL::ITS; t < TL::EXTRA_ITERS; ++t)
+          if (xd[t] != 0xFFFFFFFFu) right[xd[t] & 0xFFFFu] = xv[t];
+      }
+    }
+    __syncthreads(); // the tiles of this phase are complete
+    if (mine) {
+      // per-lane offset of column lo+di relative to the row start: own tile, or the slot on that side
+      int col[2 * R + 1];
+#pragma unroll
+      for (int di = -R; di <= R; ++di) {
+        const int c = lo + di;
+        col[di + R] = c < 0 ? -E + c + 8 : (c > 7 ? roff + c - 8 : c);
+      }
+      if (KIND == kCube125) {
+        const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
+        if (PIPE) cube125_accumulate<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
+        else cube125_accumulate_simple<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
+      } else {
+        double acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+        const int rowbase = (hi + R) * 8;
+#pragma unroll
+        for (int kk = 0; kk < TL::T; ++kk) {
+#pragma unroll
+          for (int dj = -R; dj <= R; ++dj)
+#pragma unroll
+            for (int di = -R; di <= R; ++di) {
+              const double v = tile[kk * TL::T * 8 + dj * 8 + rowbase + col[di + R]];
+#pragma unroll
+              for (int dk = -R; dk <= R; ++dk) {
+                const int k = kk - R - dk; // output plane fed through tap dk
+                if (k >= 0 && k < 8) acc[k] += cf.c[adj_slot(dk, dj, di)] * v;
+              }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
+      }
+    }
+    if (ph + 1 < nphase) __syncthreads(); // phase 1 overwrites slots phase 0 was reading
+  }
+}
+
+} // namespace
+
+// variants: 27-pt 0/6 = NW 4 (default), 5 = NW 8; 125-pt 0/5 = NW 4, 3 waves/SIMD, plain plane loop (default),
+// 6 = NW 4 and 7 = NW 8 with the software-pipelined plane loop (2 waves/SIMD)
+int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
+                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
+  const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8, wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
+  if (stencil_id == BRK_27PT_COEFF) {
+    if (variant == 5)
+      hipLaunchKernelGGL((k_cube_dense<kCube27, 8, 4>), dim3(wgs8), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+    else
+      hipLaunchKernelGGL((k_cube_dense<kCube27, 4, 5>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (variant == 6) {
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 2>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (variant == 7) {
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 8, 2>), dim3(wgs8), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else {
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, false>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  }
+  HIP_TRY(hipGetLastError());
+  return BRK_OK;
+}
+
+} // namespace brk

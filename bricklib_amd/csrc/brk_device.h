@@ -28,10 +28,12 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
                      const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const Coeffs &cf, hipStream_t st);
 
 // 13-/25-point kernels with workgroup-shared i-halos (brk_starwg.hip)
-int launch_star_wg(int stencil_id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
+int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 
 // 27-/125-point kernels with workgroup-shared i-halos (brk_cubewg.hip)
+int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
+                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 int launch_cube_wg(int stencil_id, int nw, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 

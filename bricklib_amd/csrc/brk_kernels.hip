@@ -177,12 +177,17 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   // 7-point sweeps: specialised kernels (brk_star7.hip) unless variant 1 (generic star kernel) is requested
   if ((id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) && g_variant[id] != 1)
     return launch_star7(id, g_variant[id] == 0 ? kDefaultStar7Variant : g_variant[id], adj, in, out, step, ids, first, n, cf, st);
-  if ((id == BRK_MPI13 || id == BRK_MPI25) && g_variant[id] != 1) return launch_star_wg(id, adj, in, out, step, ids, first, n, cf, st);
-  // 27-pt: shared i-halos (0.57 -> 0.54 ms at 512^3).  125-pt is fp64-VALU/LDS bound (1000 FMAs + 300 ds_reads per lane per
-  // brick); the 8-wave lockstep version measured slower (1.51 vs 1.23 ms), so it stays on the generic kernel unless
-  // variant 2 asks for the shared one.
-  if ((id == BRK_27PT_COEFF && g_variant[id] != 1) || (id == BRK_MPI125 && (g_variant[id] == 2 || g_variant[id] == 4 || g_variant[id] == 8)))
-    return launch_cube_wg(id, id == BRK_MPI125 ? g_variant[id] : 8, adj, in, out, step, ids, first, n, cf, st);
+  if ((id == BRK_MPI13 || id == BRK_MPI25) && g_variant[id] != 1) return launch_star_wg(id, g_variant[id], adj, in, out, step, ids, first, n, cf, st);
+  // 27/125-pt: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip) by default; variant 1 = generic
+  // one-wave kernel, 27-pt variant 2 and 125-pt variants 2/4/8 = padded tiles with shared i-halos (brk_cubewg.hip),
+  // 125-pt variant 3 = generic kernel with 4 waves per workgroup.  Measured at 512^3 (profiles/): 27-pt 0.555 (padded,
+  // 8 waves) -> 0.484 ms; 125-pt 1.06 (generic) -> 0.845 ms.
+  if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
+    const int v = g_variant[id];
+    if (v == 0 || (v >= 5 && v <= 7)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st);
+    if ((id == BRK_27PT_COEFF && v == 2) || (id == BRK_MPI125 && (v == 2 || v == 4 || v == 8)))
+      return launch_cube_wg(id, id == BRK_MPI125 ? v : 8, adj, in, out, step, ids, first, n, cf, st);
+  }
   switch (id) {
   case BRK_7PT_COEFF: hipLaunchKernelGGL(k_star<kStar7Coeff>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_COND7: hipLaunchKernelGGL(k_star<kStarCond7>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
@@ -193,7 +198,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   case BRK_MPI125:
     if (g_variant[id] == 3)
       hipLaunchKernelGGL((k_cube<kCube125, 4>), grid, block, 0, st, adj, in, out, step, ids, first, n, cf);
-    else
+    else // variant 1
       hipLaunchKernelGGL((k_cube<kCube125, 1>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, cf);
     break;
   }

@@ -28,8 +28,8 @@ __device__ __forceinline__ gcptr sbase(const double *p) {
   return g;
 }
 
-template <int KIND, int NW>
-__global__ __launch_bounds__(64 * NW, (StarTraits<KIND>::R == 4 ? 3 : 4)) void k_star_wg(
+template <int KIND, int NW, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
     const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
   constexpr int R = StarTraits<KIND>::R;
@@ -139,16 +139,23 @@ __global__ __launch_bounds__(64 * NW, (StarTraits<KIND>::R == 4 ? 3 : 4)) void k
 
 } // namespace
 
-int launch_star_wg(int stencil_id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
+int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
-  // 13-pt: 8 waves per workgroup (64 KiB LDS, 2 workgroups/CU).  25-pt: 12 KiB of LDS per wave, so 4-wave workgroups
-  // (48 KiB, 3 per CU = 12 waves/CU) beat 8-wave ones (96 KiB, 8 waves/CU): measured 0.80 ms vs generic 0.67 ms.
-  if (stencil_id == BRK_MPI13) {
+  // Smaller workgroups = more of them resident and less lockstep between the load and the compute phase.  Measured at
+  // 512^3: 13-pt 4 waves (32 KiB LDS, 5 groups = 20 waves/CU) 0.402 ms vs 8 waves (64 KiB, 16 waves/CU) 0.431 ms;
+  // 25-pt (12 KiB of LDS per wave, 12 waves/CU either way) 2 waves 0.532 ms vs 4 waves 0.545 ms.  Variant 2 = the larger group.
+  if (stencil_id == BRK_MPI13 && variant != 2) {
+    const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 4, 5>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (stencil_id == BRK_MPI13) {
     const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 8>), dim3(wgs), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 8, 4>), dim3(wgs), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (variant != 2) {
+    const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
   } else {
     const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 4, 3>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;

@@ -304,6 +304,22 @@ __device__ __forceinline__ void cube125_accumulate(const double *rowp, const int
   }
 }
 
+// Same without the hand pipelining (one value set, ~100 VGPRs less): for kernels that hide the LDS latency with
+// more resident waves instead.
+template <int PS, int RS>
+__device__ __forceinline__ void cube125_accumulate_simple(const double *rowp, const int (&co)[5], const Coeffs &cf,
+                                                          double *dst, int lane) {
+  double ring[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+  for (int kk = 0; kk < 12; ++kk) {
+    double v[25];
+    cube125_load_plane<PS, RS>(v, rowp, co);
+    cube125_plane(v, ring, kk, cf);
+    cube125_retire(ring, kk, dst, lane);
+    rowp += PS;
+  }
+}
+
 // One wave computes brick `b` (wave-uniform).  `tile` = this wave's private LDS slice of CubeTile<R>::ELEMS doubles.
 template <int KIND>
 __device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in,

@@ -471,3 +471,51 @@ def test_cond_stencil(oracle, golden, dev, variant):
         assert np.abs(so.dat.cpu().numpy() - want).max() <= TOL
     finally:
         lib.brk_set_variant(6, 0)
+
+
+@pytest.mark.parametrize("name,variant", [("27pt", 0), ("27pt", 1), ("27pt", 2), ("27pt", 5), ("mpi125pt", 0), ("mpi125pt", 1),
+                                          ("mpi125pt", 3), ("mpi125pt", 4), ("mpi125pt", 6), ("mpi125pt", 7),
+                                          ("mpi13pt", 0), ("mpi13pt", 1), ("mpi13pt", 2), ("mpi25pt", 0), ("mpi25pt", 1),
+                                          ("mpi25pt", 2)])
+def test_cube_kernel_variants(oracle, dev, name, variant):
+    """every 13/25/27/125-point kernel (generic, padded tiles with shared i-halos at every workgroup size, dense
+    conflict-free tiles with fallback slots and the two-phase path): row-major lists whose rows are not multiples of the workgroup (two runs inside one group),
+    padded tiled lists, shuffled lists (a break at every entry), short lists, and BrickDecomp ranges incl. the ghost ring."""
+    from bricklib_amd._lib import lib
+    from bricklib_amd.order import LIST_SKIP, tiled
+    sid = bl.STENCILS[name]
+    coeff = oracle.coeffs(129, 1) if name == "27pt" else None
+    try:
+        assert lib.brk_set_variant(sid, variant) == 0
+        grid, info = bl.init_grid((8, 7, 6), dev)
+        st = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+        st.dat.uniform_(0.0, 1.0)
+        hin = st.dat.cpu().numpy()
+        g3 = grid.reshape(6, 7, 8)
+        interior = np.ascontiguousarray(g3[1:-1, 1:-1, 1:-1]).reshape(-1).astype(np.uint32)
+        rng = np.random.default_rng(5)
+        lists = {"rows": interior, "tiled": tiled(g3[1:-1, 1:-1, 1:-1]), "shuffled": rng.permutation(interior),
+                 "all-incl-boundary": np.arange(info.nbricks, dtype=np.uint32)}
+        for q in (1, 3, 7, 9):
+            lists["first%d" % q] = interior[:q]
+        for label, lst in lists.items():
+            so = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+            bl.apply_stencil(name, bl.Brick(info, st, 0), bl.Brick(info, so, 0), ids=grid_to_device(lst, dev), coeff=coeff)
+            want = np.zeros_like(hin)
+            oracle.brick_stencil(NAMES[name], info.adj_host, hin, want, 512, ids=lst[lst != LIST_SKIP], coeff=coeff)
+            err = np.abs(so.dat.cpu().numpy() - want).max()
+            assert err <= TOL, (label, err)
+        d = bl.BrickDecomp((40, 24, 32))
+        dinfo = d.getBrickInfo(dev)
+        A, B = dinfo.allocate(512, dev), dinfo.allocate(512, dev)
+        A.dat.uniform_(0.0, 1.0)
+        A.dat[:512] = 0
+        hin2 = A.dat.cpu().numpy()
+        for rng_ in ((1, d.sep_pos[2]), (d.sep_pos[0], d.sep_pos[1]), (3, 4)):
+            B.dat.zero_()
+            bl.apply_stencil(name, bl.Brick(dinfo, A, 0), bl.Brick(dinfo, B, 0), brick_range=rng_, coeff=coeff)
+            want = np.zeros_like(hin2)
+            oracle.brick_stencil(NAMES[name], d.adj, hin2, want, 512, n=rng_[1] - rng_[0], first=rng_[0], coeff=coeff)
+            assert np.abs(B.dat.cpu().numpy() - want).max() <= TOL, rng_
+    finally:
+        lib.brk_set_variant(sid, 0)
