@@ -37,7 +37,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--n", type=int, default=512, help="cells per axis per GPU (default 512 = BASELINE config)")
     ap.add_argument("--stencil", default=None, help="override stencil (7pt|27pt|mpi7pt|mpi13pt|mpi25pt|mpi125pt)")
-    ap.add_argument("--workload", default=None, choices=[None, "single", "weak"])
+    ap.add_argument("--workload", default=None, choices=[None, "single", "weak", "strong"],
+                    help="single = 7-pt sweep of one 512^3 grid (default at 1 GPU); weak = 512^3 per rank with ghost exchange "
+                         "(default at N>1); strong = fixed global --strong-dom^3 cut into --strong-sub^3 subdomains (config 5)")
+    ap.add_argument("--strong-dom", type=int, default=1024)
+    ap.add_argument("--strong-sub", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--schedule", default="auto", choices=("auto", "deep", "surface", "plain"),
@@ -244,6 +248,56 @@ def run_weak(args, bl, dev, rank, world):
     return res, {}
 
 
+def run_strong(args, bl, dev, rank, world):
+    """strong/main.cu shape: global dom^3 in sub^3 subdomains (Z-Morton ranges per rank), one exchange + ST_ITER sweeps per
+    step; all subdomains of a rank are swept by ONE launch per sweep (bricklib_amd/strong.py)."""
+    import torch.distributed as dist
+    from bricklib_amd.strong import StrongRank, nccl_transport
+    from bricklib_amd.stencils import STENCILS
+    name = args.stencil or "mpi13pt"
+    sid = STENCILS[name]
+    K = args.steps if args.steps is not None else 10
+    W = args.warmup if args.warmup is not None else 2
+    sr = StrongRank(args.strong_dom, args.strong_sub, rank, world, dev)
+    sr.storages[0].dat.uniform_(0.0, 1.0)
+    main = torch.cuda.current_stream()
+    S = bl.stencil_iters(sid)
+
+    def step():
+        sr.exchange(nccl_transport, main)
+        sr.sweeps(sid, stream=main)
+
+    for _ in range(W):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(main)
+    for _ in range(K):
+        step()
+    e1.record(main)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    cells = float(args.strong_dom) ** 3 * S
+    local_cells = float(args.strong_sub) ** 3 * sr.nsub
+    res = {"workload": f"strong-{name}-{args.strong_dom}-{args.strong_sub}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+           "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * local_cells,
+           "kernel": "%s sweeps over %d subdomains of %d^3 (+ghost) per rank, one launch per sweep; kernel_ms = step / %d"
+                     % (name, sr.nsub, args.strong_sub, S),
+           "scaling": "strong", "cells_per_gpu": int(local_cells), "subdomains_per_rank": sr.nsub, "remote_bytes_per_rank": sr.bytes_remote}
+    return res, {}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -262,6 +316,8 @@ def main():
     workload = args.workload or ("single" if world == 1 else "weak")
     if workload == "single":
         res, extra = run_single(args, bl, dev)
+    elif workload == "strong":
+        res, extra = run_strong(args, bl, dev, rank, world)
     else:
         res, extra = run_weak(args, bl, dev, rank, world)
     if rank == 0:
@@ -270,9 +326,10 @@ def main():
         out = {
             "metric": "GStencil/s", "value": value, "unit": "GStencil/s", "n_gpus": world, "steps": res["K"],
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": args.n ** 3,
-                       **{k: res[k] for k in ("cart", "overlap", "schedule", "schedule_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank", "remote_bytes_per_rank") if k in res}},
+            "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
+                       **{k: res[k] for k in ("cart", "overlap", "schedule", "schedule_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
+                                             "remote_bytes_per_rank", "subdomains_per_rank") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],
                          "kernel_ms": res["kernel_ms"], "algorithmic_bytes_per_launch": res["alg_bytes_per_launch"]},
