@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--schedule", default="auto", choices=("auto", "deep", "surface", "plain"),
                     help="weak workload: deep = exchange hidden behind the early passes of all sweeps, surface = behind "
                          "the inner bricks of one sweep, plain = in order, auto = pick deep/surface from the measured exchange time")
+    ap.add_argument("--exchange", default="packed", choices=("packed", "direct"),
+                    help="weak workload, runs that leave the GPU: packed = one RCCL send+recv per peer through pack/unpack "
+                         "kernels, direct = one per run straight from the storage (the reference's zero-copy form)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -168,7 +171,7 @@ def run_weak(args, bl, dev, rank, world):
     stA, stB = info.allocate(512, dev), info.allocate(512, dev)
     stA.dat.uniform_(0.0, 1.0)
     A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
-    ex = Exchanger(d, stA, rank)
+    ex = Exchanger(d, stA, rank, mode=args.exchange)
     from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
     S = bl.stencil_iters(sid)
     main = torch.cuda.current_stream()
@@ -243,7 +246,7 @@ def run_weak(args, bl, dev, rank, world):
     res = {"workload": f"weak-{name}-{N}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,
            "kernel": "%s sweeps over brick lists of BrickDecomp(%d^3): %d sweeps + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S),
-           "cart": cart, "overlap": overlap, "schedule": schedule, "schedule_probe_ms": probe_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
+           "cart": cart, "overlap": overlap, "exchange": args.exchange, "schedule": schedule, "schedule_probe_ms": probe_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
            "remote_bytes_per_rank": ex.bytes_remote}
     return res, {}
 
@@ -328,7 +331,7 @@ def main():
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
-                       **{k: res[k] for k in ("cart", "overlap", "schedule", "schedule_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
+                       **{k: res[k] for k in ("cart", "overlap", "exchange", "schedule", "schedule_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],

@@ -138,29 +138,64 @@ def local_links(bDecomp, storages, rank_maps, ranks):
 
 class Exchanger:
     """Ghost exchange of ONE rank's storage (the `ev.exchange()` / `bDecomp.exchange(bStorage)` call of
-    weak/main.cpp:172-183).  Self-neighbour runs become device links; the rest are grouped P2P ops."""
+    weak/main.cpp:172-183).  Self-neighbour runs become device links; the rest goes over torch.distributed:
+      mode "direct" -- one send + one recv per run, straight from/into the storage (the reference's zero-copy form,
+                       include/brick-mpi.h:476-484; up to 42 messages per exchange);
+      mode "packed" -- runs bound for the same peer are packed into one buffer by brk_link_copy, ONE send + ONE recv per
+                       peer (at most 7 on a 2x2x2 grid), unpacked by brk_link_copy: fewer, larger xGMI transfers.
+    Both sides enumerate a peer's runs in run-index order (the reference's message tags), so buffers need no header."""
 
-    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False):
-        self.d, self.st, self.rank, self.group = bDecomp, storage, rank, group
+    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False, mode="direct"):
+        assert mode in ("direct", "packed")
+        self.d, self.st, self.rank, self.group, self.mode = bDecomp, storage, rank, group, mode
         self.cpu = storage.dat.device.type == "cpu"
         if self.cpu and not allow_cpu_plumbing:
             raise RuntimeError("Exchanger on CPU tensors is test plumbing only (gloo); pass allow_cpu_plumbing=True")
         links, remote = local_links(bDecomp, {rank: storage}, {rank: bDecomp.rank_map}, {rank})
-        self._cpu_links = []
+        self.remote = [(q, src) for _, q, src in remote]
+        step, esz, dat = storage.step, storage.dat.element_size(), storage.dat
+        self.bytes_remote = sum(bDecomp.ghost[q]["len"] for q, _ in self.remote) * step * esz
+        # per-peer buffers and copy plans: (source element offset, destination element offset, elements)
+        self.send_buf, self.recv_buf, pack, unpack = {}, {}, [], []
+        if mode == "packed":
+            peers = sorted({src for _, src in self.remote} | {bDecomp.rank_map[bDecomp.skin[q]["neighbor"]] for q, _ in self.remote})
+            for p_ in peers:
+                rq = [q for q, src in self.remote if src == p_]
+                sq = [q for q, _ in self.remote if bDecomp.rank_map[bDecomp.skin[q]["neighbor"]] == p_]
+                self.recv_buf[p_] = torch.empty(sum(bDecomp.ghost[q]["len"] for q in rq) * step, dtype=dat.dtype, device=dat.device)
+                self.send_buf[p_] = torch.empty(sum(bDecomp.skin[q]["len"] for q in sq) * step, dtype=dat.dtype, device=dat.device)
+                o = 0
+                for q in sq:
+                    n = bDecomp.skin[q]["len"] * step
+                    pack.append((dat, bDecomp.skin[q]["pos"] * step, self.send_buf[p_], o, n))
+                    o += n
+                o = 0
+                for q in rq:
+                    n = bDecomp.ghost[q]["len"] * step
+                    unpack.append((self.recv_buf[p_], o, dat, bDecomp.ghost[q]["pos"] * step, n))
+                    o += n
+        self._cpu_links, self._cpu_pack, self._cpu_unpack = [], pack, unpack
         if self.cpu:
-            step = storage.step
             for g, s in zip(bDecomp.ghost, bDecomp.skin):
                 if bDecomp.rank_map[g["neighbor"]] == rank:
                     self._cpu_links.append((g["pos"] * step, s["pos"] * step, g["len"] * step))
-            self.table = None
+            self.table = self.unpack_table = None
         else:
-            self.table = LinkTable(links, storage.dat.device)
-        self.remote = [(q, src) for _, q, src in remote]
-        self.bytes_remote = sum(bDecomp.ghost[q]["len"] for q, _ in self.remote) * storage.step * 8
+            ptr = lambda t, o: t.data_ptr() + o * esz
+            # same-rank links and the packing copies are independent: one launch
+            self.table = LinkTable(links + [(ptr(a, ao), ptr(b, bo), n * esz) for a, ao, b, bo, n in pack], dat.device)
+            self.unpack_table = LinkTable([(ptr(a, ao), ptr(b, bo), n * esz) for a, ao, b, bo, n in unpack], dat.device)
 
     def _ops(self):
         import torch.distributed as dist
         step, dat, ops = self.st.step, self.st.dat, []
+        if self.mode == "packed":
+            for p_ in sorted(self.recv_buf):
+                if self.recv_buf[p_].numel():
+                    ops.append(dist.P2POp(dist.irecv, self.recv_buf[p_], p_, self.group))
+                if self.send_buf[p_].numel():
+                    ops.append(dist.P2POp(dist.isend, self.send_buf[p_], p_, self.group))
+            return ops
         for q, src in self.remote:   # same run order on every rank: pairwise matching is by issue order
             g, s = self.d.ghost[q], self.d.skin[q]
             dst = self.d.rank_map[s["neighbor"]]
@@ -168,21 +203,41 @@ class Exchanger:
             ops.append(dist.P2POp(dist.isend, dat[s["pos"] * step:(s["pos"] + s["len"]) * step], dst, self.group))
         return ops
 
-    def exchange(self, stream=None):
-        """Asynchronous on `stream` (default: current stream) for device storages."""
+    def exchange_begin(self, stream=None):
+        """same-rank links + packing (device: one brk_link_copy launch)"""
         if self.cpu:
             for dpos, spos, n in self._cpu_links:
                 self.st.dat[dpos:dpos + n] = self.st.dat[spos:spos + n].clone()
+            for a, ao, b, bo, n in self._cpu_pack:
+                b[bo:bo + n] = a[ao:ao + n]
         else:
             self.table.run(stream)
-        if self.remote:
-            import torch.distributed as dist
-            if self.cpu or stream is None:
+
+    def exchange_transport(self, stream=None):
+        """grouped send/recv over torch.distributed (backend nccl = RCCL over xGMI; gloo in the CPU tests)"""
+        if not self.remote:
+            return
+        import torch.distributed as dist
+        if self.cpu or stream is None:
+            reqs = dist.batch_isend_irecv(self._ops())
+            for r in reqs:
+                r.wait()
+        else:
+            with torch.cuda.stream(stream):
                 reqs = dist.batch_isend_irecv(self._ops())
                 for r in reqs:
                     r.wait()
-            else:
-                with torch.cuda.stream(stream):
-                    reqs = dist.batch_isend_irecv(self._ops())
-                    for r in reqs:
-                        r.wait()
+
+    def exchange_end(self, stream=None):
+        """unpacking (packed mode only)"""
+        if self.cpu:
+            for a, ao, b, bo, n in self._cpu_unpack:
+                b[bo:bo + n] = a[ao:ao + n]
+        elif self.unpack_table.n:
+            self.unpack_table.run(stream)
+
+    def exchange(self, stream=None):
+        """Asynchronous on `stream` (default: current stream) for device storages."""
+        self.exchange_begin(stream)
+        self.exchange_transport(stream)
+        self.exchange_end(stream)

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, dom, q):
+def _worker(rank, world, port, dom, q, mode):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -27,7 +27,7 @@ def _worker(rank, world, port, dom, q):
         # every element encodes (rank, brick, element) so a misrouted run is caught exactly
         v = torch.arange(d.nbricks * 512, dtype=torch.float64) + rank * 1e9
         st.dat.copy_(v)
-        ex = Exchanger(d, st, rank, allow_cpu_plumbing=True)
+        ex = Exchanger(d, st, rank, allow_cpu_plumbing=True, mode=mode)
         ex.exchange()
         dist.barrier()
         q.put((rank, st.dat.numpy().copy(), len(ex.remote)))
@@ -35,13 +35,13 @@ def _worker(rank, world, port, dom, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_exchange_two_ranks_gloo(oracle, world):
+@pytest.mark.parametrize("world,mode", [(2, "direct"), (4, "direct"), (2, "packed"), (4, "packed"), (8, "packed"), (8, "direct")])
+def test_exchange_two_ranks_gloo(oracle, world, mode):
     dom = (32, 16, 24)
-    port = 29500 + (os.getpid() % 2000) + world
+    port = 29500 + (os.getpid() % 2000) + world + (10 if mode == "packed" else 0)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dom, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dom, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
