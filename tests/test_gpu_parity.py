@@ -551,3 +551,42 @@ def test_packed_exchange_tables_virtual_ranks(oracle, dev, nranks):
     oracle.exchange(od, want, [oracle.populate_rank_map(cart, rank_to_coo(r, cart)) for r in range(nranks)], 512)
     for r in range(nranks):
         assert (sts[r].dat.cpu().numpy() == want[r]).all(), r
+
+
+@pytest.mark.parametrize("name", ["7pt", "mpi13pt"])
+def test_large_1024_cubed_addressing(oracle, dev, name):
+    """1024^3 cells = 2.2 M bricks, 9 GB per field: byte offsets beyond 2^32 in every kernel path (id list, 64-bit brick
+    base + 32-bit lane offsets).  Constant-field property over the whole grid + bricks sampled from the top of the id
+    range against the oracle on a compacted copy of their neighbourhoods."""
+    from bricklib_amd.order import tiled
+    SB = 130
+    grid, info = bl.init_grid((SB, SB, SB), dev)
+    ids = tiled(grid.reshape(SB, SB, SB)[1:-1, 1:-1, 1:-1])
+    ids_dev = grid_to_device(ids, dev)
+    coeff = oracle.coeffs(129, 1) if name == "7pt" else None
+    x, sx = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(2))
+    assert x.dat.numel() * 8 > 2 ** 33
+    B = lambda s: bl.Brick(info, s, 0)
+    x.dat.fill_(1.5)
+    bl.apply_stencil(name, B(x), B(sx), ids=ids_dev, coeff=coeff)
+    wsum = coeff[:7].sum() if name == "7pt" else 0.4 + 6 * 0.07 + 6 * 0.03
+    real = torch.from_numpy(ids[ids != 0xFFFFFFFF].astype(np.int64)).to(dev)
+    top = real[real > info.nbricks - 3 * SB * SB]            # the last interior planes: offsets > 8.9 GB
+    assert top.numel() > 0 and (sx.dat.view(-1, 512)[top] - 1.5 * wsum).abs().max().item() <= 1e-12
+    assert (sx.dat.view(-1, 512)[real[:: 997]] - 1.5 * wsum).abs().max().item() <= 1e-12
+    # random data, sampled bricks: compact their 27-neighbourhoods into a small storage the oracle can take
+    x.dat.uniform_(0.0, 1.0)
+    bl.apply_stencil(name, B(x), B(sx), ids=ids_dev, coeff=coeff)
+    rng = np.random.default_rng(9)
+    real_h = real.cpu().numpy()
+    sub = np.concatenate([rng.choice(real_h, 192, replace=False), rng.choice(top.cpu().numpy(), 64, replace=False)])
+    nb = info.adj_host[sub]                                   # [n][27] global ids
+    uniq, inv = np.unique(nb.reshape(-1), return_inverse=True)
+    small_adj = np.zeros((uniq.size, 27), dtype=np.uint32)   # only the sampled bricks' rows are used
+    local_ids = inv.reshape(-1, 27)[:, 13].astype(np.uint32)
+    small_adj[local_ids] = inv.reshape(-1, 27).astype(np.uint32)
+    hin = x.dat.view(-1, 512)[torch.from_numpy(uniq.astype(np.int64)).to(dev)].cpu().numpy().reshape(-1)
+    want = np.zeros_like(hin)
+    oracle.brick_stencil(NAMES[name], small_adj, hin, want, 512, ids=local_ids, coeff=coeff)
+    got = sx.dat.view(-1, 512)[torch.from_numpy(sub.astype(np.int64)).to(dev)].cpu().numpy()
+    assert np.abs(got - want.reshape(-1, 512)[local_ids]).max() <= TOL
