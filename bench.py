@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--schedule", default="auto", choices=("auto", "deep", "surface", "plain"),
                     help="weak workload: deep = exchange hidden behind the early passes of all sweeps, surface = behind "
-                         "the inner bricks of one sweep, plain = in order, auto = pick deep/surface from the measured exchange time")
+                         "the inner bricks of one sweep, plain = in order, auto = cheapest of the three for the measured exchange time")
     ap.add_argument("--exchange", default="packed", choices=("packed", "direct"),
                     help="weak workload, runs that leave the GPU: packed = one RCCL send+recv per peer through pack/unpack "
                          "kernels, direct = one per run straight from the storage (the reference's zero-copy form)")
@@ -174,14 +174,13 @@ def run_weak(args, bl, dev, rank, world):
     ex = Exchanger(d, stA, rank, mode=args.exchange)
     from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
     S = bl.stencil_iters(sid)
+    sweep_ms = None
     main = torch.cuda.current_stream()
     comm = torch.cuda.Stream()
     schedule = "plain" if args.no_overlap else args.schedule
     probe_ms = None
     if schedule == "auto":
-        # measure, don't guess: the exchange alone, max over ranks.  "surface" hides it behind the inner bricks of one
-        # sweep on either side (~0.7 ms of compute at 512^3) at no cost; "deep" hides it behind the early passes of all
-        # sweeps (~2 ms) for ~4 % more compute time (thicker shells, more launches).
+        # measure, don't guess: the exchange alone (max over ranks) ...
         t0_, t1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for it in range(7):
             if it == 2:
@@ -192,12 +191,26 @@ def run_weak(args, bl, dev, rank, world):
             ex.exchange(main)
         t1_.record(main)
         torch.cuda.synchronize()
-        x = torch.tensor([t0_.elapsed_time(t1_) / 5], dtype=torch.float64, device=dev)
+        # ... and one full sweep, to price the schedules: measured on one MI355X at 512^3 (profiles/r01_f_*), relative to
+        # the in-order cycle T = S sweeps: surface costs +6 % and hides up to 0.21 T of exchange, deep costs +10.6 % and
+        # hides up to 0.59 T; an overlapped exchange is taken to run 1.3x slower than alone (it shares HBM with the sweeps).
+        from bricklib_amd.stencils import apply_stencil
+        all_ids = SweepLists(d, dev).all
+        s0_, s1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for it in range(5):
+            if it == 2:
+                s0_.record(main)
+            apply_stencil(sid, A, B, ids=all_ids, stream=main)
+        s1_.record(main)
+        torch.cuda.synchronize()
+        x = torch.tensor([t0_.elapsed_time(t1_) / 5, s0_.elapsed_time(s1_) / 3], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(x, op=dist.ReduceOp.MAX)
-        probe_ms = float(x.item())
-        inner_ms = BYTES_PER_UPDATE * float(N - 16) ** 3 / (HBM_COPY_GBS * 1e9 * 0.8) * 1e3
-        schedule = "deep" if probe_ms > 1.5 * inner_ms else "surface"
+        probe_ms, sweep_ms = float(x[0].item()), float(x[1].item())
+        T = S * sweep_ms
+        cost = {"plain": T + probe_ms, "surface": 1.06 * T + max(0.0, 1.3 * probe_ms - 0.21 * T),
+                "deep": 1.106 * T + max(0.0, 1.3 * probe_ms - 0.59 * T)}
+        schedule = min(cost, key=cost.get)
     overlap = schedule != "plain"
     state = {}
     if schedule == "deep":
@@ -246,7 +259,7 @@ def run_weak(args, bl, dev, rank, world):
     res = {"workload": f"weak-{name}-{N}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,
            "kernel": "%s sweeps over brick lists of BrickDecomp(%d^3): %d sweeps + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S),
-           "cart": cart, "overlap": overlap, "exchange": args.exchange, "schedule": schedule, "schedule_probe_ms": probe_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
+           "cart": cart, "overlap": overlap, "exchange": args.exchange, "schedule": schedule, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
            "remote_bytes_per_rank": ex.bytes_remote}
     return res, {}
 
@@ -331,7 +344,7 @@ def main():
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
-                       **{k: res[k] for k in ("cart", "overlap", "exchange", "schedule", "schedule_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
+                       **{k: res[k] for k in ("cart", "overlap", "exchange", "schedule", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],

@@ -19,18 +19,24 @@ def _pad(a, n):
 
 
 def slabs(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True):
-    """Per-XCD pieces of the tiled order of `ids3` ([nk][nj][ni] brick ids): XCD x gets its own slab of j-rows, swept
-    in blocks of <= rows_per_block rows over all k, i fastest.  pad_rows: rows are padded with LIST_SKIP to a multiple
-    of 8 entries so that a workgroup (8 consecutive entries) never straddles two rows."""
+    """Per-XCD pieces of the tiled order of `ids3` ([nk][nj][ni] brick ids): XCD x gets its own slab of nj // nxcd
+    j-rows, swept in blocks of <= rows_per_block rows over all k, i fastest; the nj % nxcd left-over rows are cut along k
+    instead, one k-range per XCD, so that every XCD gets the same amount of work (66 rows: 8 each + 2 rows x 1/8 of the
+    planes, instead of two XCDs with 9 rows setting the pace).  pad_rows: a row whose length is not a multiple of 8 gets ONE LIST_SKIP entry
+    behind it, so that two rows never meet inside a workgroup without an idle wave between them (the kernels park
+    fallback halos in an idle wave's LDS slot; two active non-neighbours side by side cost a second phase)."""
     ids3 = np.asarray(ids3).astype(np.uint32)
     nk, nj, ni = ids3.shape
     if pad_rows and ni % 8:
-        ids3 = np.concatenate([ids3, np.full((nk, nj, 8 - ni % 8), LIST_SKIP, dtype=np.uint32)], axis=2)
-    bounds = [(nj * x) // nxcd for x in range(nxcd + 1)]
+        ids3 = np.concatenate([ids3, np.full((nk, nj, 1), LIST_SKIP, dtype=np.uint32)], axis=2)
+    base, rem = divmod(nj, nxcd)
     out = []
     for x in range(nxcd):
-        parts = [np.ascontiguousarray(ids3[:, j0:min(j0 + rows_per_block, bounds[x + 1]), :]).reshape(-1)
-                 for j0 in range(bounds[x], bounds[x + 1], rows_per_block)]
+        parts = [np.ascontiguousarray(ids3[:, j0:min(j0 + rows_per_block, (x + 1) * base), :]).reshape(-1)
+                 for j0 in range(x * base, (x + 1) * base, rows_per_block)]
+        if rem:
+            k0, k1 = (nk * x) // nxcd, (nk * (x + 1)) // nxcd
+            parts.append(np.ascontiguousarray(ids3[k0:k1, nj - rem:, :]).reshape(-1))
         out.append(np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint32))
     return out
 
@@ -57,25 +63,44 @@ def tiled(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True):
     return assemble(slabs(ids3, rows_per_block, nxcd, pad_rows), nxcd=nxcd)
 
 
-def decomp_lists(d, rows_per_block=8):
-    """Brick lists for the weak/strong sweep schedule of a BrickDecomp `d` (see drivers.weak_cycle):
-    inner   -- [1,sep0), tiled                       (never reads a ghost brick)
-    shell   -- [sep0,sep2) surface + ghost, id order (thin regions)
-    surface -- [sep0,sep1) id order
-    all / domain -- inner + shell / inner + surface, interleaved per XCD."""
-    nb = [d.dims[a] // 8 - 2 * (d.depth // 8) for a in range(3)]   # inner extent in bricks (i,j,k)
-    inner = 1 + np.arange(nb[0] * nb[1] * nb[2], dtype=np.int64).reshape(nb[2], nb[1], nb[0])
-    assert inner.size == d.sep_pos[0] - 1
-    inner_s = slabs(inner, rows_per_block)
-    shell = np.arange(d.sep_pos[0], d.sep_pos[2], dtype=np.uint32)
-    surface = np.arange(d.sep_pos[0], d.sep_pos[1], dtype=np.uint32)
-    return {"inner": assemble(inner_s), "shell": shell, "surface": surface,
-            "all": assemble(inner_s, chunks(shell)),          # [1,sep2): subdomain + ghost ring
-            "domain": assemble(inner_s, chunks(surface))}     # [1,sep1): the subdomain itself
-
-
 def _box(grid, lo, hi):
     return grid[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
+
+
+def shell_list(g, lo, hi, ilo, ihi, rows_per_block=8):
+    """Tiled list of the bricks of box [lo,hi) of the logical grid `g` that are outside box [ilo,ihi): two k-slabs in the
+    per-XCD slab order, the four j/i side walls row by row."""
+    if any(ihi[a] <= ilo[a] for a in range(3)):
+        return tiled(_box(g, lo, hi), rows_per_block)
+    klo = slabs(_box(g, lo, [hi[0], hi[1], ilo[2]]), rows_per_block)
+    khi = slabs(_box(g, [lo[0], lo[1], ihi[2]], hi), rows_per_block)
+    rest = [_box(g, [lo[0], lo[1], ilo[2]], [hi[0], ilo[1], ihi[2]]),        # j-low / j-high
+            _box(g, [lo[0], ihi[1], ilo[2]], [hi[0], hi[1], ihi[2]]),
+            _box(g, [lo[0], ilo[1], ilo[2]], [ilo[0], ihi[1], ihi[2]]),      # i-low / i-high
+            _box(g, [ihi[0], ilo[1], ilo[2]], [hi[0], ihi[1], ihi[2]])]
+    rest = np.concatenate([np.ascontiguousarray(r).reshape(-1) for r in rest])
+    return assemble(klo, khi, chunks(rest))
+
+
+def decomp_lists(d, rows_per_block=8):
+    """Brick lists for the weak/strong sweep schedule of a BrickDecomp `d` (see drivers.weak_cycle), all in the geometric
+    (logical-grid) tiled order -- i fastest across ghost / surface / inner bricks alike, so runs of i-neighbours share
+    halos whatever their ids are:
+    inner   -- [1,sep0): bricks that never read a ghost brick
+    shell   -- [sep0,sep2): surface + ghost ring            surface -- [sep0,sep1)
+    all     -- [1,sep2): subdomain + ghost ring             domain  -- [1,sep1): the subdomain itself."""
+    g = np.asarray(d.grid).astype(np.uint32)
+    T = [g.shape[2], g.shape[1], g.shape[0]]
+    gb = d.depth // 8                                   # ghost width in bricks
+    lo0, hi0 = [0] * 3, T
+    lo1, hi1 = [gb] * 3, [T[a] - gb for a in range(3)]
+    lo2, hi2 = [2 * gb] * 3, [T[a] - 2 * gb for a in range(3)]
+    has_inner = all(hi2[a] > lo2[a] for a in range(3))
+    inner = tiled(_box(g, lo2, hi2), rows_per_block) if has_inner else np.zeros(0, dtype=np.uint32)
+    assert (inner != LIST_SKIP).sum() == d.sep_pos[0] - 1
+    return {"inner": inner, "shell": shell_list(g, lo0, hi0, lo2, hi2, rows_per_block),
+            "surface": shell_list(g, lo1, hi1, lo2, hi2, rows_per_block),
+            "all": tiled(_box(g, lo0, hi0), rows_per_block), "domain": tiled(_box(g, lo1, hi1), rows_per_block)}
 
 
 def trapezoid_lists(d, sweeps, rows_per_block=8):
@@ -94,17 +119,7 @@ def trapezoid_lists(d, sweeps, rows_per_block=8):
         hi = [T[a] - lo[a] for a in range(3)]
         ilo = [t + 1] * 3
         ihi = [T[a] - t - 1 for a in range(3)]
-        if any(ihi[a] <= ilo[a] for a in range(3)):   # the cone has closed: everything waits for the exchange
-            inner.append(np.zeros(0, dtype=np.uint32))
-            shell.append(tiled(_box(g, lo, hi), rows_per_block))
-            continue
-        inner.append(tiled(_box(g, ilo, ihi), rows_per_block))
-        klo = slabs(_box(g, lo, [hi[0], hi[1], ilo[2]]), rows_per_block)
-        khi = slabs(_box(g, [lo[0], lo[1], ihi[2]], hi), rows_per_block)
-        rest = [_box(g, [lo[0], lo[1], ilo[2]], [hi[0], ilo[1], ihi[2]]),        # j-low / j-high
-                _box(g, [lo[0], ihi[1], ilo[2]], [hi[0], hi[1], ihi[2]]),
-                _box(g, [lo[0], ilo[1], ilo[2]], [ilo[0], ihi[1], ihi[2]]),      # i-low / i-high
-                _box(g, [ihi[0], ilo[1], ilo[2]], [hi[0], ihi[1], ihi[2]])]
-        rest = np.concatenate([np.ascontiguousarray(r).reshape(-1) for r in rest])
-        shell.append(assemble(klo, khi, chunks(rest)))
+        has = all(ihi[a] > ilo[a] for a in range(3))   # False: the cone has closed, everything waits for the exchange
+        inner.append(tiled(_box(g, ilo, ihi), rows_per_block) if has else np.zeros(0, dtype=np.uint32))
+        shell.append(shell_list(g, lo, hi, ilo, ihi, rows_per_block))
     return inner, shell

@@ -70,8 +70,9 @@ int brk_stencil_apply_range(int stencil_id, const uint32_t *adj_dev, const doubl
                             brk_stream s);
 /* Same over an explicit list of brick ids, e.g. the reference's `grid` array or any slice of it
  * (stencils/3axis.hip.cpp:36-39 `b = grid[tk][tj][ti]`, strong/main.cu:85-99).  Entries equal to BRK_LIST_SKIP are
- * ignored; hosts use them to pad rows so that every group of 8 consecutive entries is a run of i-neighbours (the kernels
- * share i-faces inside such a group). */
+ * ignored; hosts use them to separate rows of a traversal order: the kernels share i-halos between consecutive entries that
+ * are i-neighbours (4 or 8 entries per workgroup) and handle two consecutive non-neighbours correctly but more slowly than
+ * two runs with a skipped entry between them (bricklib_amd/order.py). */
 #define BRK_LIST_SKIP 0xFFFFFFFFu
 int brk_stencil_apply_list(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
                            size_t step_elems, const uint32_t *brick_ids_dev, uint32_t n, const double *coeff_host,
