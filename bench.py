@@ -192,7 +192,7 @@ def run_weak(args, bl, dev, rank, world):
         t1_.record(main)
         torch.cuda.synchronize()
         # ... and one full sweep, to price the schedules: measured on one MI355X at 512^3 (profiles/r01_f_*), relative to
-        # the in-order cycle T = S sweeps: surface costs +6 % and hides up to 0.21 T of exchange, deep costs +10.6 % and
+        # the in-order cycle T = S sweeps: surface costs +4.5 % and hides up to 0.21 T of exchange, deep costs +9 % and
         # hides up to 0.59 T; an overlapped exchange is taken to run 1.3x slower than alone (it shares HBM with the sweeps).
         from bricklib_amd.stencils import apply_stencil
         all_ids = SweepLists(d, dev).all
@@ -208,8 +208,8 @@ def run_weak(args, bl, dev, rank, world):
             dist.all_reduce(x, op=dist.ReduceOp.MAX)
         probe_ms, sweep_ms = float(x[0].item()), float(x[1].item())
         T = S * sweep_ms
-        cost = {"plain": T + probe_ms, "surface": 1.06 * T + max(0.0, 1.3 * probe_ms - 0.21 * T),
-                "deep": 1.106 * T + max(0.0, 1.3 * probe_ms - 0.59 * T)}
+        cost = {"plain": T + probe_ms, "surface": 1.045 * T + max(0.0, 1.3 * probe_ms - 0.21 * T),
+                "deep": 1.09 * T + max(0.0, 1.3 * probe_ms - 0.59 * T)}
         schedule = min(cost, key=cost.get)
     overlap = schedule != "plain"
     state = {}
