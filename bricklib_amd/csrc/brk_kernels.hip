@@ -63,6 +63,21 @@ __global__ __launch_bounds__(64 * WPW) void k_cube(const uint32_t *__restrict__ 
                    threadIdx.x & 63);
 }
 
+// stencil given as data (brk_stencil_apply_taps): one wave per brick, generic staging, one LDS read + FMA per tap and plane
+template <int R, int WPW>
+__global__ __launch_bounds__(64 * WPW) void k_taps(const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                                   double *__restrict__ out, size_t step, const uint32_t *__restrict__ ids,
+                                                   uint32_t first, uint32_t n, Taps tp) {
+  __shared__ double lds[WPW * CubeTile<R>::ELEMS];
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t slot = wg * WPW + (threadIdx.x >> 6);
+  if (slot >= n) return;
+  const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
+  if (b == BRK_LIST_SKIP) return;
+  taps_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, b, tp, threadIdx.x & 63);
+}
+
 // ================================================================================================================
 // Region copies (pack / unpack / same-GPU halo links).  grid = (chunks, links); 16-B lanes, 64 KiB per block.
 // ================================================================================================================
@@ -246,6 +261,36 @@ extern "C" int brk_stencil_apply_list(int id, const uint32_t *adj, const double 
                                       const uint32_t *ids, uint32_t n, const double *coeff_host, brk_stream s) {
   if (n && !ids) return brk_fail(BRK_EINVAL, "null brick id list");
   return launch_stencil(id, adj, in, out, step, ids, 0, n, coeff_host, s);
+}
+
+extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
+                                      uint32_t first, uint32_t n, uint32_t ntaps, const int32_t *offsets_host,
+                                      const double *weights_host, brk_stream s) {
+  if (!adj || !in || !out || in == out) return brk_fail(BRK_EINVAL, "bad device pointers");
+  if (step < 512) return brk_fail(BRK_EINVAL, "step_elems %zu < 512", step);
+  if (ntaps == 0 || ntaps > (uint32_t)kMaxTaps || !offsets_host || !weights_host)
+    return brk_fail(BRK_EINVAL, "1..%d taps with host offset and weight arrays expected (got %u)", kMaxTaps, ntaps);
+  if (n == 0) return BRK_OK;
+  Taps tp;
+  tp.n = (int)ntaps;
+  tp.radius = 1;
+  for (uint32_t t = 0; t < ntaps; ++t)
+    for (int a = 0; a < 3; ++a) {
+      const int o = offsets_host[3 * t + a];
+      if (o < -2 || o > 2) return brk_fail(BRK_EINVAL, "tap %u: offset %d on axis %d outside [-2,2]", t, o, a);
+      if (o < -1 || o > 1) tp.radius = 2;
+    }
+  for (uint32_t t = 0; t < ntaps; ++t) {
+    const int di = offsets_host[3 * t], dj = offsets_host[3 * t + 1], dk = offsets_host[3 * t + 2];
+    tp.rel[t] = tp.radius == 1 ? tap_rel<1>(di, dj, dk) : tap_rel<2>(di, dj, dk);
+    tp.w[t] = weights_host[t];
+  }
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
+  if (tp.radius == 1) hipLaunchKernelGGL((k_taps<1, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);
+  else hipLaunchKernelGGL((k_taps<2, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);
+  HIP_TRY(hipGetLastError());
+  return BRK_OK;
 }
 
 extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *in, double *out, size_t step,

@@ -47,3 +47,19 @@ def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coef
         b0, b1 = brick_range if brick_range is not None else (0, bIn.bInfo.nbricks)
         check(lib.brk_stencil_apply_range(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, int(b0), int(b1), cp,
                                           _stream(stream)))
+
+
+def apply_taps(taps, bIn, bOut, ids=None, brick_range=None, stream=None):
+    """A linear stencil given as data (brk_stencil_apply_taps): taps = [((di, dj, dk), weight), ...] with offsets in
+    [-2, 2], applied in list order; e.g. the output of bricklib_amd.spec.load_spec(...).taps(constants)."""
+    off = np.ascontiguousarray([list(o) for o, _ in taps], dtype=np.int32).reshape(-1)
+    w = np.ascontiguousarray([float(x) for _, x in taps], dtype=np.float64)
+    offp, wp = off.ctypes.data_as(C.POINTER(C.c_int32)), w.ctypes.data_as(C.POINTER(C.c_double))
+    adj = bIn.bInfo.adj
+    if ids is not None:
+        check(lib.brk_stencil_apply_taps(_ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids), 0, ids.numel(),
+                                         len(taps), offp, wp, _stream(stream)))
+    else:
+        b0, b1 = brick_range if brick_range is not None else (0, bIn.bInfo.nbricks)
+        check(lib.brk_stencil_apply_taps(_ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, None, int(b0), int(b1 - b0),
+                                         len(taps), offp, wp, _stream(stream)))

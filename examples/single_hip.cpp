@@ -60,6 +60,16 @@ __global__ void d3cond_brick_trans(unsigned (*grid)[STRIDEB][STRIDEB], BrickDev 
   brick("cond.py", VSVEC, (BDIM), (VFOLD), b);
 }
 
+// A stencil the library has no hand-written kernel for: examples/lap19.py (19 points, written for this example).
+// tools/brkscatter reads the script as data and emits the generic tap path.
+__global__ void lap19_brick(unsigned (*grid)[STRIDEB][STRIDEB], BrickDev bIn, BrickDev bOut, bElem *coeff) {
+  long tk = GB + hipBlockIdx_z;
+  long tj = GB + hipBlockIdx_y;
+  long ti = GB + hipBlockIdx_x;
+  unsigned b = grid[tk][tj][ti];
+  brick("lap19.py", VSVEC, (BDIM), (VFOLD), b);
+}
+
 int main() {
   bElem *coeff = (bElem *)malloc(COEFF_SIZE * sizeof(bElem));
   {
@@ -160,6 +170,27 @@ int main() {
     hipLaunchKernelGGL(d3cond_brick_trans, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
     gpuCheck(hipDeviceSynchronize());
     check("brick() cond kernel");
+  }
+  // (4) a user-written script (lap19.py) through the generic tap path
+  {
+#pragma omp parallel for collapse(2)
+    for (long k = PADDING + GZ; k < PADDING + GZ + N; ++k)
+      for (long j = PADDING + GZ; j < PADDING + GZ + N; ++j)
+        for (long i = PADDING + GZ; i < PADDING + GZ + N; ++i) {
+          bElem acc = coeff[0] * arr_in[k][j][i];
+          for (int s = 1; s >= -1; s -= 2) {
+            acc += coeff[1] * (arr_in[k][j][i + s] + arr_in[k][j + s][i] + arr_in[k + s][j][i]);
+            for (int t = 1; t >= -1; t -= 2)
+              acc += coeff[2] * (arr_in[k][j + t][i + s] + arr_in[k + t][j][i + s] + arr_in[k + t][j + s][i]);
+          }
+          arr_out[k][j][i] = acc;
+        }
+    BrickDev dIn{binfo_dev, bstorage_dev.dat.get(), bstorage_dev.step};
+    BrickDev dOut{binfo_dev, bstorage_dev.dat.get() + bsize, bstorage_dev.step};
+    dim3 block(NB, NB, NB), thread(64);
+    hipLaunchKernelGGL(lap19_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
+    gpuCheck(hipDeviceSynchronize());
+    check("brick() lap19 kernel (script read as data)");
   }
   return 0;
 }

@@ -320,11 +320,12 @@ __device__ __forceinline__ void cube125_accumulate_simple(const double *rowp, co
   }
 }
 
-// One wave computes brick `b` (wave-uniform).  `tile` = this wave's private LDS slice of CubeTile<R>::ELEMS doubles.
-template <int KIND>
-__device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in,
-                                           double *__restrict__ out, size_t step, uint32_t b, const Coeffs &cf, int lane) {
-  constexpr int R = CubeTraits<KIND>::R;
+// Load brick `b` (wave-uniform) with its full halo of radius R into `tile` (this wave's private LDS slice of
+// CubeTile<R>::ELEMS doubles): own brick and the 6 faces by structured coalesced loads, edge/corner cells through the
+// descriptor table.
+template <int R>
+__device__ __forceinline__ void cube_stage(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                           size_t step, uint32_t b, int lane) {
   using TL = CubeTile<R>;
   const int hi = lane >> 3, lo = lane & 7;
   const uint32_t arow = adj[(size_t)b * 27 + (lane < 27 ? lane : 13)];
@@ -377,6 +378,16 @@ __device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restr
   for (int t = 0; t < TL::EXTRA_ITERS; ++t)
     if (xd[t] != 0xFFFFFFFFu) tile[xd[t] & 0xFFFFu] = xv[t];
   wave_lds_sync();
+}
+
+// One wave computes brick `b` (wave-uniform).  `tile` = this wave's private LDS slice of CubeTile<R>::ELEMS doubles.
+template <int KIND>
+__device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                           double *__restrict__ out, size_t step, uint32_t b, const Coeffs &cf, int lane) {
+  constexpr int R = CubeTraits<KIND>::R;
+  using TL = CubeTile<R>;
+  const int hi = lane >> 3, lo = lane & 7;
+  cube_stage<R>(tile, adj, in, step, b, lane);
 
   // ---- scatter-form accumulate; lane = (j=hi, i=lo)
   double acc[8];
@@ -407,6 +418,77 @@ __device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restr
   for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Linear stencils given as data: out[p] = sum_t w[t] * in[p + (di,dj,dk)[t]], any subset of the 125-point cube
+// (|offset| <= 2 per axis), taps applied in list order.  The table travels as a kernel argument (1.5 KB).
+// rel[t] = offset of tap t relative to the centre cell inside a CubeTile<R>: (dk * T + dj) * P + di.
+// One LDS read + one FMA per tap and output plane: the general path, slower than the hand-scheduled kernels above.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMaxTaps = 125;
+struct Taps {
+  int n, radius;
+  int rel[kMaxTaps];
+  double w[kMaxTaps];
+};
+
+template <int R>
+__host__ __device__ constexpr int tap_rel(int di, int dj, int dk) { return (dk * CubeTile<R>::T + dj) * CubeTile<R>::P + di; }
+
+template <int R>
+__device__ __forceinline__ void taps_brick(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                           double *__restrict__ out, size_t step, uint32_t b, const Taps &tp, int lane) {
+  using TL = CubeTile<R>;
+  const int hi = lane >> 3, lo = lane & 7;
+  cube_stage<R>(tile, adj, in, step, b, lane);
+  const double *c = tile + TL::at(R, hi + R, lo + R);
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+#pragma unroll 1
+  for (int t = 0; t < tp.n; ++t) {
+    const int o = tp.rel[t];
+    const double w = tp.w[t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += w * c[k * TL::T * TL::P + o];
+  }
+  double *dst = out + (size_t)b * step;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
+}
+
+// user-kernel entry point (what tools/brkscatter emits for a stencil script that is not one of the built-in ones)
+template <int R, int MAXW = 4>
+__device__ __forceinline__ void brick_apply_taps(const uint32_t *adj, const double *in, double *out, size_t step, uint32_t b,
+                                                 const Taps &tp) {
+  __shared__ double lds[MAXW * CubeTile<R>::ELEMS];
+  taps_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, __builtin_amdgcn_readfirstlane(b), tp,
+                threadIdx.x & 63);
+}
+
+// The same with the tap table known at compile time (NTAPS taps; drivers of the reference #define N, offsets `rel`, weights `w` in registers): fully unrolled.
+template <int R, int NTAPS, int MAXW = 4>
+__device__ __forceinline__ void brick_apply_taps_static(const uint32_t *adj, const double *in, double *out, size_t step,
+                                                        uint32_t b, const int (&rel)[NTAPS], const double (&w)[NTAPS]) {
+  using TL = CubeTile<R>;
+  __shared__ double lds[MAXW * TL::ELEMS];
+  const int lane = threadIdx.x & 63, hi = lane >> 3, lo = lane & 7;
+  double *tile = lds + (threadIdx.x >> 6) * TL::ELEMS;
+  b = __builtin_amdgcn_readfirstlane(b);
+  cube_stage<R>(tile, adj, in, step, b, lane);
+  const double *c = tile + TL::at(R, hi + R, lo + R);
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int t = 0; t < NTAPS; ++t) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += w[t] * c[k * TL::T * TL::P + rel[t]];
+  }
+  double *dst = out + (size_t)b * step;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Entry points for user kernels (one wave per brick, any number of waves per block up to MAXW).

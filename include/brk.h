@@ -85,6 +85,14 @@ int brk_stencil_apply_list(int stencil_id, const uint32_t *adj_dev, const double
 int brk_stencil_apply_box(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
                           size_t step_elems, uint32_t base, const uint32_t tot_bricks[3], const uint32_t lo[3],
                           const uint32_t cnt[3], const double *coeff_host, brk_stream s);
+/* A linear stencil given as data -- the capability of the reference's code generator for scripts that are not one of the
+ * built-in ones (codegen/vecscatter evaluating stencils/<name>.py; bricklib_amd/spec.py reads such scripts into this form):
+ *   out[p] = sum_t weights[t] * in[p + (offsets[3t], offsets[3t+1], offsets[3t+2])]   (i, j, k offsets, each in [-2,2],
+ *   1 <= ntaps <= 125, taps added in list order).  Bricks: brick_ids_dev[0..n) when non-NULL (BRK_LIST_SKIP allowed), else
+ *   ids first..first+n-1.  General path: one LDS read + FMA per tap and point, not tuned like the built-in stencils. */
+int brk_stencil_apply_taps(const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
+                           const uint32_t *brick_ids_dev, uint32_t first, uint32_t n, uint32_t ntaps,
+                           const int32_t *offsets_host, const double *weights_host, brk_stream s);
 /* Kernel variant selection for experiments/benchmarks: 0 = default. */
 int brk_set_variant(int stencil_id, int variant);
 

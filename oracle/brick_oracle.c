@@ -455,6 +455,24 @@ void orc_brick_stencil_naive(int id, const uint32_t *adj, const double *in, doub
   }
 }
 
+/* A linear stencil given as tap data, through the accessor semantics (what the reference's generated code computes for
+ * `calc = c0 * in(i+a, j+b, k+c) + ...`, stencils/7pt.py:19-27, codegen evaluating the expression tap by tap): taps are
+ * added in list order starting from the first product. */
+void orc_brick_taps(const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids, long n,
+                    int ntaps, const int *offsets /* [ntaps][3] = (di,dj,dk) */, const double *weights) {
+  for (long q = 0; q < n; ++q) {
+    uint32_t b = ids[q];
+    for (int k = 0; k < BS; ++k)
+      for (int j = 0; j < BS; ++j)
+        for (int i = 0; i < BS; ++i) {
+          double acc = 0.0;
+          for (int t = 0; t < ntaps; ++t)
+            acc += weights[t] * orc_brick_at(adj, in, step, b, k + offsets[3 * t + 2], j + offsets[3 * t + 1], i + offsets[3 * t]);
+          out[(size_t)b * step + k * 64 + j * 8 + i] = acc;
+        }
+  }
+}
+
 /* ------------------------------------------------------------------------------------------
  * BitSet (ref: include/bitset.h:20-126): +p -> bit p, -p -> bit 31+p; operator! swaps signs.
  * ---------------------------------------------------------------------------------------- */

@@ -63,6 +63,9 @@ class Oracle:
                                         C.POINTER(C.c_double)]
         L.orc_brick_stencil.argtypes = [C.c_int, _u32p, _f64p, _f64p, C.c_size_t, C.c_void_p, C.c_long, C.c_uint32,
                                         C.POINTER(C.c_double)]
+        L.orc_brick_taps.argtypes = [_u32p, _f64p, _f64p, C.c_size_t, _u32p, C.c_long, C.c_int,
+                                     np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS"), _f64p]
+        L.orc_brick_taps.restype = None
         L.orc_brick_stencil_naive.argtypes = [C.c_int, _u32p, _f64p, _f64p, C.c_size_t, _u32p, C.c_long,
                                               C.POINTER(C.c_double)]
         L.orc_stencil_radius.argtypes = [C.c_int]
@@ -148,6 +151,13 @@ class Oracle:
         else:
             idp = None
         self.L.orc_brick_stencil(sid, adj, bin_, bout, step, idp, n, first, cp[0] if cp else None)
+
+    def brick_taps(self, adj, bin_, bout, step, ids, taps):
+        """taps: [((di,dj,dk), weight), ...]"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        off = np.ascontiguousarray([o for o, _ in taps], dtype=np.int32).reshape(-1)
+        w = np.ascontiguousarray([x for _, x in taps], dtype=np.float64)
+        self.L.orc_brick_taps(adj, bin_, bout, step, ids, ids.size, len(taps), off, w)
 
     def brick_stencil_naive(self, sid, adj, bin_, bout, step, ids, coeff=None):
         cp = _coeff(coeff)

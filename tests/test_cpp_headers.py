@@ -103,3 +103,4 @@ def test_example_driver_runs():
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300).stdout.decode()
     assert "brick() kernel: result match" in out and "brk_stencil_apply_list: result match" in out, out
     assert "brick() cond kernel: result match" in out, out
+    assert "brick() lap19 kernel (script read as data): result match" in out, out   # user-written script, generic tap path

@@ -590,3 +590,62 @@ def test_large_1024_cubed_addressing(oracle, dev, name):
     oracle.brick_stencil(NAMES[name], small_adj, hin, want, 512, ids=local_ids, coeff=coeff)
     got = sx.dat.view(-1, 512)[torch.from_numpy(sub.astype(np.int64)).to(dev)].cpu().numpy()
     assert np.abs(got - want.reshape(-1, 512)[local_ids]).max() <= TOL
+
+
+def _taps_cases(oracle):
+    rng = np.random.default_rng(17)
+    coeff = oracle.coeffs(129, 1)
+    seven = [((0, 0, 0), coeff[0]), ((1, 0, 0), coeff[1]), ((-1, 0, 0), coeff[2]), ((0, 1, 0), coeff[3]), ((0, -1, 0), coeff[4]),
+             ((0, 0, 1), coeff[5]), ((0, 0, -1), coeff[6])]
+    cube = lambda r: [((di, dj, dk), float(rng.uniform(-1, 1))) for dk in range(-r, r + 1) for dj in range(-r, r + 1)
+                      for di in range(-r, r + 1)]
+    c27, c125 = cube(1), cube(2)
+    lopsided = [c125[q] for q in rng.choice(125, 19, replace=False)]
+    return {"seven": seven, "cube27": c27, "cube125": c125, "lopsided19": lopsided, "single-shifted": [((2, -2, 1), 1.0)]}
+
+
+@pytest.mark.parametrize("case", ["seven", "cube27", "cube125", "lopsided19", "single-shifted"])
+def test_stencil_given_as_taps(oracle, dev, case):
+    """brk_stencil_apply_taps: arbitrary linear stencils inside the 125-point cube, list (with skipped
+    entries) and range forms, against the oracle's accessor-semantics evaluation; the 7-point taps also against the
+    built-in kernel."""
+    from bricklib_amd.order import LIST_SKIP, tiled
+    from bricklib_amd.stencils import apply_taps
+    taps = _taps_cases(oracle)[case]
+    grid, info = bl.init_grid((9, 7, 6), dev)
+    st = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    st.dat.uniform_(0.0, 1.0)
+    so = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    lst = tiled(grid.reshape(6, 7, 9)[1:-1, 1:-1, 1:-1])
+    assert (lst == LIST_SKIP).any()
+    apply_taps(taps, bl.Brick(info, st, 0), bl.Brick(info, so, 0), ids=grid_to_device(lst, dev))
+    hin = st.dat.cpu().numpy()
+    want = np.zeros_like(hin)
+    real = lst[lst != LIST_SKIP]
+    oracle.brick_taps(info.adj_host, hin, want, 512, real, taps)
+    assert np.abs(so.dat.cpu().numpy() - want).max() <= TOL
+    if case == "seven":
+        sb = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+        bl.apply_stencil("7pt", bl.Brick(info, st, 0), bl.Brick(info, sb, 0), ids=grid_to_device(lst, dev), coeff=oracle.coeffs(129, 1))
+        assert (sb.dat - so.dat).abs().max().item() <= TOL
+    # range form over a BrickDecomp numbering incl. the ghost ring (neighbours that are the dummy brick 0)
+    d = bl.BrickDecomp((24, 16, 32))
+    dinfo = d.getBrickInfo(dev)
+    A, B = dinfo.allocate(512, dev), dinfo.allocate(512, dev)
+    A.dat.uniform_(0.0, 1.0)
+    A.dat[:512] = 0
+    apply_taps(taps, bl.Brick(dinfo, A, 0), bl.Brick(dinfo, B, 0), brick_range=(1, d.sep_pos[2]))
+    hin2 = A.dat.cpu().numpy()
+    want2 = np.zeros_like(hin2)
+    oracle.brick_taps(d.adj, hin2, want2, 512, np.arange(1, d.sep_pos[2], dtype=np.uint32), taps)
+    assert np.abs(B.dat.cpu().numpy() - want2).max() <= TOL
+
+
+def test_taps_argument_checks(dev):
+    from bricklib_amd._lib import BrkError
+    from bricklib_amd.stencils import apply_taps
+    grid, info = bl.init_grid((4, 4, 4), dev)
+    st, so = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(2))
+    for bad in ([((3, 0, 0), 1.0)], [((0, 0, 0), 1.0)] * 126):
+        with pytest.raises(BrkError):
+            apply_taps(bad, bl.Brick(info, st, 0), bl.Brick(info, so, 0), brick_range=(0, 1))
