@@ -21,7 +21,7 @@ __device__ __forceinline__ gcptr sbase(const double *p) {
 }
 
 template <int KIND, int NW>
-__global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : (NW == 8 ? 2 : 3))) void k_cube_wg(
+__global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : 2)) void k_cube_wg(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
     const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
   constexpr int R = CubeTraits<KIND>::R;
