@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--n", type=int, default=512, help="cells per axis per GPU (default 512 = BASELINE config)")
+    ap.add_argument("--n", "--cells", dest="n", type=int, default=512, help="cells per axis per GPU (default 512 = BASELINE config)")
     ap.add_argument("--stencil", default=None, help="override stencil (7pt|27pt|mpi7pt|mpi13pt|mpi25pt|mpi125pt)")
     ap.add_argument("--workload", default=None, choices=[None, "single", "weak", "strong"],
                     help="single = 7-pt sweep of one 512^3 grid (default at 1 GPU); weak = 512^3 per rank with ghost exchange "
@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--exchange", default="packed", choices=("packed", "direct"),
                     help="weak workload, runs that leave the GPU: packed = one RCCL send+recv per peer through pack/unpack "
                          "kernels, direct = one per run straight from the storage (the reference's zero-copy form)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="nccl = RCCL over xGMI (one rank per GPU); gloo = REHEARSAL of the multi-rank control flow with several "
+                         "ranks sharing one GPU, ghost bytes staged through host memory (numbers are not a measurement)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -171,10 +174,21 @@ def run_weak(args, bl, dev, rank, world):
     stA, stB = info.allocate(512, dev), info.allocate(512, dev)
     stA.dat.uniform_(0.0, 1.0)
     A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
-    ex = Exchanger(d, stA, rank, mode=args.exchange)
+    ex = Exchanger(d, stA, rank, mode=args.exchange, staged=args.backend == "gloo")
     from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
     S = bl.stencil_iters(sid)
     sweep_ms = None
+
+    def global_sum():
+        """sum of the field over all ranks' subdomains (bricks [1, sep1)); the MPI_* star stencils have weights that add up
+        to 1, so on the periodic global domain every sweep conserves it -- a size-independent check of the whole exchange +
+        sweep schedule that also runs at 8 x 512^3"""
+        t = stA.dat[512:512 * d.sep_pos[1]].sum().reshape(1)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    sum0 = global_sum()
     main = torch.cuda.current_stream()
     comm = torch.cuda.Stream()
     schedule = "plain" if args.no_overlap else args.schedule
@@ -255,8 +269,11 @@ def run_weak(args, bl, dev, rank, world):
     if world > 1:
         dist.barrier()
     exchange_ms = xs.elapsed_time(x1) / 5
+    sum1 = global_sum()
+    # weights of the MPI_* stencils add up to 1 (fake.h:11-33): 0.4+6(.1); .4+6(.07+.03); .1+6(.06+.045+.03+.015); C0..C9 x multiplicities
+    drift = abs(sum1 - sum0) / abs(sum0) if name in ("mpi7pt", "mpi13pt", "mpi25pt", "mpi125pt") else None
     cells = float(N) ** 3 * S * world
-    res = {"workload": f"weak-{name}-{N}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+    res = {"workload": f"weak-{name}-{N}", "conservation_rel_drift": drift, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,
            "kernel": "%s sweeps over brick lists of BrickDecomp(%d^3): %d sweeps + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S),
            "cart": cart, "overlap": overlap, "exchange": args.exchange, "schedule": schedule, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
@@ -323,12 +340,17 @@ def main():
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     import bricklib_amd as bl
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()      # rehearsal: ranks share the GPUs that exist
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     workload = args.workload or ("single" if world == 1 else "weak")
     if workload == "single":
         res, extra = run_single(args, bl, dev)
@@ -345,7 +367,7 @@ def main():
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
                        **{k: res[k] for k in ("cart", "overlap", "exchange", "schedule", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
-                                             "remote_bytes_per_rank", "subdomains_per_rank") if k in res}},
+                                             "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],
                          "kernel_ms": res["kernel_ms"], "algorithmic_bytes_per_launch": res["alg_bytes_per_launch"]},

@@ -145,9 +145,10 @@ class Exchanger:
                        peer (at most 7 on a 2x2x2 grid), unpacked by brk_link_copy: fewer, larger xGMI transfers.
     Both sides enumerate a peer's runs in run-index order (the reference's message tags), so buffers need no header."""
 
-    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False, mode="direct"):
+    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False, mode="direct", staged=False):
         assert mode in ("direct", "packed")
         self.d, self.st, self.rank, self.group, self.mode = bDecomp, storage, rank, group, mode
+        self.staged = staged      # rehearsal transport, see exchange_transport()
         self.cpu = storage.dat.device.type == "cpu"
         if self.cpu and not allow_cpu_plumbing:
             raise RuntimeError("Exchanger on CPU tensors is test plumbing only (gloo); pass allow_cpu_plumbing=True")
@@ -218,6 +219,27 @@ class Exchanger:
         if not self.remote:
             return
         import torch.distributed as dist
+        if self.staged:
+            # REHEARSAL ONLY (bench.py --backend gloo): several ranks share one GPU, where RCCL cannot run, so the packed
+            # buffers take a detour through host memory and gloo.  Exercises everything around the transport call --
+            # rank maps, packing order, schedules, stream hand-over -- with real processes; never the default.
+            assert self.mode == "packed"
+            s_ = stream or torch.cuda.current_stream()
+            s_.synchronize()
+            host_s = {p_: b.cpu() for p_, b in self.send_buf.items()}
+            host_r = {p_: torch.empty(b.numel(), dtype=b.dtype) for p_, b in self.recv_buf.items()}
+            ops = []
+            for p_ in sorted(host_r):
+                if host_r[p_].numel():
+                    ops.append(dist.P2POp(dist.irecv, host_r[p_], p_, self.group))
+                if host_s[p_].numel():
+                    ops.append(dist.P2POp(dist.isend, host_s[p_], p_, self.group))
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            with torch.cuda.stream(s_):
+                for p_, b in self.recv_buf.items():
+                    b.copy_(host_r[p_], non_blocking=False)
+            return
         if self.cpu or stream is None:
             reqs = dist.batch_isend_irecv(self._ops())
             for r in reqs:

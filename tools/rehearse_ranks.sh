@@ -1,0 +1,24 @@
+#!/bin/bash
+# Rehearsal of bench.py's multi-rank control flow on a ONE-GPU box: N processes share the GPU, ghost bytes go through host
+# memory + gloo (bench.py --backend gloo).  Checks the conservation property, not speed.
+set -o pipefail
+mkdir -p gpurun_out/rehearse
+port=29520
+for cfg in "2 plain" "2 surface" "2 deep" "4 deep" "4 surface" "6 deep"; do
+  set -- $cfg
+  port=$((port + 1))
+  out=gpurun_out/rehearse/n$1_$2
+  timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $1 --master-addr 127.0.0.1 --master-port $port \
+    bench.py --gpus $1 --backend gloo --cells 256 --steps 3 --warmup 1 --no-cpu-baseline --schedule $2 > $out.out 2> $out.err
+  rc=$?
+  if [ $rc -ne 0 ]; then echo "N=$1 $2 FAILED rc=$rc"; tail -15 $out.err; exit 1; fi
+  python3 - $out.out "$cfg" <<'PY'
+import json, sys
+line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
+d = json.loads(line)
+c = d["config"]
+print(sys.argv[2], "cart", c["cart"], "schedule", c["schedule"], "remote MB", round(c["remote_bytes_per_rank"] / 1e6, 1),
+      "conservation drift", c["conservation_rel_drift"])
+assert c["conservation_rel_drift"] < 1e-12
+PY
+done
