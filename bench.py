@@ -285,7 +285,7 @@ def run_strong(args, bl, dev, rank, world):
     """strong/main.cu shape: global dom^3 in sub^3 subdomains (Z-Morton ranges per rank), one exchange + ST_ITER sweeps per
     step; all subdomains of a rank are swept by ONE launch per sweep (bricklib_amd/strong.py)."""
     import torch.distributed as dist
-    from bricklib_amd.strong import StrongRank, nccl_transport
+    from bricklib_amd.strong import StrongRank, nccl_transport, staged_transport
     from bricklib_amd.stencils import STENCILS
     name = args.stencil or "mpi13pt"
     sid = STENCILS[name]
@@ -296,8 +296,18 @@ def run_strong(args, bl, dev, rank, world):
     main = torch.cuda.current_stream()
     S = bl.stencil_iters(sid)
 
+    transport = staged_transport if args.backend == "gloo" else nccl_transport
+
+    def global_sum():   # see run_weak: the MPI_* stencils conserve the sum of the periodic global field
+        v = sr.storages[0].dat.view(sr.nsub, sr.nb, 512)[:, 1:sr.d.sep_pos[1]].sum().reshape(1)
+        if world > 1:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        return float(v.item())
+
+    sum0 = global_sum()
+
     def step():
-        sr.exchange(nccl_transport, main)
+        sr.exchange(transport, main)
         sr.sweeps(sid, stream=main)
 
     for _ in range(W):
@@ -321,13 +331,15 @@ def run_strong(args, bl, dev, rank, world):
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    sum1 = global_sum()
+    drift = abs(sum1 - sum0) / abs(sum0) if name in ("mpi7pt", "mpi13pt", "mpi25pt", "mpi125pt") else None
     cells = float(args.strong_dom) ** 3 * S
     local_cells = float(args.strong_sub) ** 3 * sr.nsub
     res = {"workload": f"strong-{name}-{args.strong_dom}-{args.strong_sub}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * local_cells,
            "kernel": "%s sweeps over %d subdomains of %d^3 (+ghost) per rank, one launch per sweep; kernel_ms = step / %d"
                      % (name, sr.nsub, args.strong_sub, S),
-           "scaling": "strong", "cells_per_gpu": int(local_cells), "subdomains_per_rank": sr.nsub, "remote_bytes_per_rank": sr.bytes_remote}
+           "scaling": "strong", "conservation_rel_drift": drift, "cells_per_gpu": int(local_cells), "subdomains_per_rank": sr.nsub, "remote_bytes_per_rank": sr.bytes_remote}
     return res, {}
 
 

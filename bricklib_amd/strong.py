@@ -166,3 +166,22 @@ def loopback_transport(all_ranks):
         for p in sr.peers:
             all_ranks[p].recv_buf[sr.rank].copy_(sr.send_buf[p])
     return go
+
+
+def staged_transport(sr, stream=None):
+    """REHEARSAL ONLY (bench.py --backend gloo): ranks share one GPU, buffers detour through host memory and gloo."""
+    import torch.distributed as dist
+    (stream or torch.cuda.current_stream()).synchronize()
+    host_s = {p: sr.send_buf[p].cpu() for p in sr.peers}
+    host_r = {p: torch.empty(sr.recv_buf[p].numel(), dtype=torch.float64) for p in sr.peers}
+    ops = []
+    for p in sr.peers:
+        if host_r[p].numel():
+            ops.append(dist.P2POp(dist.irecv, host_r[p], p))
+        if host_s[p].numel():
+            ops.append(dist.P2POp(dist.isend, host_s[p], p))
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+    with torch.cuda.stream(stream or torch.cuda.current_stream()):
+        for p in sr.peers:
+            sr.recv_buf[p].copy_(host_r[p])

@@ -4,7 +4,7 @@
 set -o pipefail
 mkdir -p gpurun_out/rehearse
 port=29520
-for cfg in "2 plain" "2 surface" "2 deep" "4 deep" "4 surface" "6 deep"; do
+for cfg in "2 plain" "2 surface" "2 deep" "4 deep" "4 surface"; do   # at most 4 ranks: a one-GPU test box allows 6 processes on the card, launcher included
   set -- $cfg
   port=$((port + 1))
   out=gpurun_out/rehearse/n$1_$2
@@ -19,6 +19,23 @@ d = json.loads(line)
 c = d["config"]
 print(sys.argv[2], "cart", c["cart"], "schedule", c["schedule"], "remote MB", round(c["remote_bytes_per_rank"] / 1e6, 1),
       "conservation drift", c["conservation_rel_drift"])
+assert c["conservation_rel_drift"] < 1e-12
+PY
+done
+# strong workload: global 256^3 in 64^3 subdomains over 2 and 3 ranks
+for np_ in 2 3; do
+  port=$((port + 1))
+  out=gpurun_out/rehearse/strong_n$np_
+  timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $np_ --master-addr 127.0.0.1 --master-port $port \
+    bench.py --gpus $np_ --backend gloo --workload strong --strong-dom 256 --strong-sub 64 --steps 3 --warmup 1 --no-cpu-baseline > $out.out 2> $out.err
+  rc=$?
+  if [ $rc -ne 0 ]; then echo "strong N=$np_ FAILED rc=$rc"; tail -15 $out.err; exit 1; fi
+  python3 - $out.out "strong $np_" <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+c = d["config"]
+print(sys.argv[2], "subdomains/rank", c["subdomains_per_rank"], "remote MB", round(c["remote_bytes_per_rank"] / 1e6, 1), "conservation drift",
+      c["conservation_rel_drift"])
 assert c["conservation_rel_drift"] < 1e-12
 PY
 done
