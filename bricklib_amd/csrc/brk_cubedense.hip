@@ -21,14 +21,6 @@
 namespace brk {
 namespace {
 
-typedef const __attribute__((address_space(1))) double *gcptr;
-typedef __attribute__((address_space(1))) double *gptr;
-__device__ __forceinline__ gcptr sbase(const double *p) {
-  gcptr g = (gcptr)p;
-  asm volatile("" : "+s"(g)); // SGPR base + 32-bit lane offset addressing (see brk_star7.hip)
-  return g;
-}
-
 template <int R>
 struct DenseTile {
   static constexpr int T = 8 + 2 * R;

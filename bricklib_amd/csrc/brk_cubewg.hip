@@ -12,14 +12,6 @@
 namespace brk {
 namespace {
 
-typedef const __attribute__((address_space(1))) double *gcptr;
-typedef __attribute__((address_space(1))) double *gptr;
-__device__ __forceinline__ gcptr sbase(const double *p) {
-  gcptr g = (gcptr)p;
-  asm volatile("" : "+s"(g)); // SGPR base + 32-bit lane offset addressing (see brk_star7.hip)
-  return g;
-}
-
 template <int KIND, int NW>
 __global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : 2)) void k_cube_wg(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,

@@ -19,8 +19,21 @@ constexpr int kWG = 64 * kWavesPerWG;
     if (e_ != hipSuccess) return brk_fail(BRK_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-// Launchers of the specialised 7-point kernels (brk_star7.hip).  variant: 2 = one brick per wave,
-// 3 = persistent waves with register prefetch of the next brick.
+// Global-address-space pointers whose (wave-uniform) value is hidden from the optimiser: accesses through them are
+// emitted as global_load/global_store with an SGPR base and a 32-bit per-lane offset.  Without this hipcc folds
+// base+lane into 64-bit VGPR addresses (two VGPRs and two VALU ops per access).  The address space must be kept
+// explicit: a generic pointer after the asm would turn the accesses into flat_* instructions, which force
+// vmcnt(0)/lgkmcnt(0) waits.
+typedef const __attribute__((address_space(1))) double *gcptr;
+typedef __attribute__((address_space(1))) double *gptr;
+__device__ __forceinline__ gcptr sbase(const double *p) {
+  gcptr g = (gcptr)p;
+  asm volatile("" : "+s"(g));
+  return g;
+}
+
+// Launchers of the specialised 7-point kernels (brk_star7.hip).  variant: 2 = one brick per wave, every face gathered;
+// 5 / 6 = workgroups of 8 / 4 waves sharing i-faces through LDS.
 int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step,
                  const uint32_t *ids, uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 
@@ -31,7 +44,8 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
 int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 
-// 27-/125-point kernels with workgroup-shared i-halos (brk_cubewg.hip)
+// 27-/125-point kernels: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip), and the earlier padded
+// tiles with shared i-halos (brk_cubewg.hip)
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 int launch_cube_wg(int stencil_id, int nw, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,

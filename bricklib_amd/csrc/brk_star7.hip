@@ -22,20 +22,6 @@ struct Faces {
   double own[8], km, kp, jm, jp, im, ip;
 };
 
-// Global-address-space pointers whose (wave-uniform) value is hidden from the optimiser: accesses through them
-// are emitted as global_load/global_store with an SGPR base and a 32-bit per-lane offset.  Without this hipcc
-// folds base+lane into 64-bit VGPR addresses (two VGPRs and two VALU ops per access).  The address space must be
-// kept explicit: a generic pointer after the asm would turn the accesses into flat_* instructions, which force
-// vmcnt(0)/lgkmcnt(0) waits.
-typedef const __attribute__((address_space(1))) double *gcptr;
-typedef __attribute__((address_space(1))) double *gptr;
-
-__device__ __forceinline__ gcptr scalar_base(const double *p) {
-  gcptr g = (gcptr)p;
-  asm volatile("" : "+s"(g));
-  return g;
-}
-
 // Face-neighbour ids of brick b.  b is wave-uniform, so these are scalar (s_load) reads of the adjacency row:
 // they are counted on lgkmcnt, not vmcnt, and therefore never entangle with the vector loads/stores in flight.
 struct Nbr {
@@ -60,10 +46,10 @@ __device__ __forceinline__ void issue_loads(Faces &f, const double *__restrict__
   const uint32_t n_km = __builtin_amdgcn_readfirstlane(nb.km), n_kp = __builtin_amdgcn_readfirstlane(nb.kp);
   const uint32_t n_jm = __builtin_amdgcn_readfirstlane(nb.jm), n_jp = __builtin_amdgcn_readfirstlane(nb.jp);
   const uint32_t n_im = __builtin_amdgcn_readfirstlane(nb.im), n_ip = __builtin_amdgcn_readfirstlane(nb.ip);
-  const gcptr self = scalar_base(in + (size_t)b * step);
-  const gcptr p_km = scalar_base(in + (size_t)n_km * step), p_kp = scalar_base(in + (size_t)n_kp * step);
-  const gcptr p_jm = scalar_base(in + (size_t)n_jm * step), p_jp = scalar_base(in + (size_t)n_jp * step);
-  const gcptr p_im = scalar_base(in + (size_t)n_im * step), p_ip = scalar_base(in + (size_t)n_ip * step);
+  const gcptr self = sbase(in + (size_t)b * step);
+  const gcptr p_km = sbase(in + (size_t)n_km * step), p_kp = sbase(in + (size_t)n_kp * step);
+  const gcptr p_jm = sbase(in + (size_t)n_jm * step), p_jp = sbase(in + (size_t)n_jp * step);
+  const gcptr p_im = sbase(in + (size_t)n_im * step), p_ip = sbase(in + (size_t)n_ip * step);
 #pragma unroll
   for (int k = 0; k < 8; ++k) f.own[k] = self[k * 64 + lane];
   f.km = p_km[7 * 64 + lane];          // plane k=7 of the brick below
@@ -110,7 +96,7 @@ __device__ __forceinline__ void compute_store(const double *tile, const Faces &f
                                               const Coeffs &cf) {
   const int hi = lane >> 3, lo = lane & 7;
   gptr dst = (gptr)dst_;
-  asm volatile("" : "+s"(dst)); // see scalar_base()
+  asm volatile("" : "+s"(dst)); // see sbase()
   // per-lane tile offsets of the four in-plane neighbours in plane 0 (plane k adds k*kPlane, an immediate)
   const int o_jm = hi * 8 + lo, o_jp = (hi + 2) * 8 + lo;
   const int o_im = lo > 0 ? (hi + 1) * 8 + lo - 1 : 80 + hi;
@@ -237,31 +223,31 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
   bool share_im = false, share_ip = false;
   if (active) {
     const Nbr nb = load_nbr(adj, b);
-    const gcptr self = scalar_base(in + (size_t)b * step);
+    const gcptr self = sbase(in + (size_t)b * step);
 #pragma unroll
     for (int k = 0; k < 8; ++k) f.own[k] = self[k * 64 + lane];
     __builtin_amdgcn_sched_barrier(0); // own loads are in flight before anything waits for the adjacency row
     // siblings: entry slot-1 / slot+1 when they belong to this workgroup
     share_im = has_prev && __builtin_amdgcn_readfirstlane(nb.im) == b_prev;
     share_ip = has_next && __builtin_amdgcn_readfirstlane(nb.ip) == b_next;
-    const gcptr p_km = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.km) * step);
-    const gcptr p_kp = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.kp) * step);
-    const gcptr p_jm = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.jm) * step);
-    const gcptr p_jp = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.jp) * step);
+    const gcptr p_km = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.km) * step);
+    const gcptr p_kp = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.kp) * step);
+    const gcptr p_jm = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.jm) * step);
+    const gcptr p_jp = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.jp) * step);
     f.km = p_km[7 * 64 + lane];
     f.kp = p_kp[lane];
     f.jm = p_jm[hi * 64 + 7 * 8 + lo];
     f.jp = p_jp[hi * 64 + lo];
     f.im = 0.0;
     f.ip = 0.0;
-    if (!share_im) f.im = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.im) * step)[hi * 64 + lo * 8 + 7];
-    if (!share_ip) f.ip = scalar_base(in + (size_t)__builtin_amdgcn_readfirstlane(nb.ip) * step)[hi * 64 + lo * 8];
+    if (!share_im) f.im = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.im) * step)[hi * 64 + lo * 8 + 7];
+    if (!share_ip) f.ip = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.ip) * step)[hi * 64 + lo * 8];
     stage(tile, f, lane);
   }
   __syncthreads(); // every wave's brick is staged; sibling tiles are now readable
   if (!active) return;
   gptr dst = (gptr)(out + (size_t)b * step);
-  asm volatile("" : "+s"(dst)); // see scalar_base()
+  asm volatile("" : "+s"(dst)); // see sbase()
   const int o_jm = hi * 8 + lo, o_jp = (hi + 2) * 8 + lo;
   const int o_im = lo > 0 ? (hi + 1) * 8 + lo - 1 : (share_im ? -kTile + (hi + 1) * 8 + 7 : 80 + hi);
   const int o_ip = lo < 7 ? (hi + 1) * 8 + lo + 1 : (share_ip ? kTile + (hi + 1) * 8 : 88 + hi);

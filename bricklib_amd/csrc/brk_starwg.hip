@@ -20,14 +20,6 @@ struct WgTile {
   static constexpr int TILE = 8 * PLANE;
 };
 
-typedef const __attribute__((address_space(1))) double *gcptr;
-typedef __attribute__((address_space(1))) double *gptr;
-__device__ __forceinline__ gcptr sbase(const double *p) {
-  gcptr g = (gcptr)p;
-  asm volatile("" : "+s"(g)); // keep SGPR base + 32-bit lane offset addressing (see brk_star7.hip)
-  return g;
-}
-
 template <int KIND, int NW, int OCC>
 __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,

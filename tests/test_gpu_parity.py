@@ -227,7 +227,7 @@ def _weak_virtual(oracle, dev, name, nranks, dom, schedule):
 @pytest.mark.parametrize("variant", [1, 2, 5, 6])
 @pytest.mark.parametrize("name", ["7pt", "mpi7pt"])
 def test_star7_kernel_variants(oracle, dev, name, variant):
-    """every 7-point kernel variant (generic / one brick per wave / persistent pipelines), list and range forms,
+    """every 7-point kernel variant (generic / one brick per wave / 8- and 4-wave groups sharing i-faces), list and range forms,
     list lengths around the pipeline's corner cases (fewer entries than waves, odd/even trip counts)."""
     from bricklib_amd._lib import lib
     sid = bl.STENCILS[name]
@@ -250,7 +250,7 @@ def test_star7_kernel_variants(oracle, dev, name, variant):
             oracle.brick_stencil(NAMES[name], bInfo.adj_host, hin, want, 512, ids=sub[sub != LIST_SKIP], coeff=coeff)
             got = st.dat.cpu().numpy().reshape(-1, 1024)[:, 512:]
             assert np.abs(got - want.reshape(-1, 512)).max() <= TOL, (n,)
-        # range form on the BrickDecomp layout (large enough that persistent waves take several trips)
+        # range form on the BrickDecomp layout (ghost ring included: neighbours that are the dummy brick 0)
         dom = (160, 152, 168)
         d = bl.BrickDecomp(dom)
         info = d.getBrickInfo(dev)
