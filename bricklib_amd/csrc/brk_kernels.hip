@@ -12,6 +12,9 @@
 //     faces) then meet in the same 4 MiB L2.
 // HBM-bound by design: 16 B of compulsory traffic per lattice update, no MFMA (not a contraction).
 #include <cstring>
+#include <mutex>
+#include <vector>
+#include <algorithm>
 
 #include "brk_device.h"
 
@@ -251,6 +254,70 @@ extern "C" int brk_set_variant(int id, int v) {
   return BRK_OK;
 }
 
+// Id list of a structured box in the traversal order of bricklib_amd/order.py (per-XCD slabs of j-rows swept over all k,
+// left-over rows cut along k, one skipped entry behind rows that are not a multiple of 8, XCD parts padded to equal length).
+// Lists are owned by the library: a small per-process cache keyed by the geometry, least recently used entry replaced.
+struct BoxList {
+  uint32_t key[10];
+  uint32_t *dev;
+  uint32_t n;
+  uint64_t stamp;
+};
+constexpr int kBoxCache = 8;
+BoxList g_box[kBoxCache];
+uint64_t g_box_clock = 0;
+std::mutex g_box_mutex;
+
+int box_list(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const uint32_t **ids, uint32_t *n) {
+  std::lock_guard<std::mutex> lock(g_box_mutex);
+  const uint32_t key[10] = {base, tot[0], tot[1], tot[2], lo[0], lo[1], lo[2], cnt[0], cnt[1], cnt[2]};
+  int victim = 0;
+  for (int q = 0; q < kBoxCache; ++q) {
+    if (g_box[q].dev && std::memcmp(g_box[q].key, key, sizeof key) == 0) {
+      g_box[q].stamp = ++g_box_clock;
+      *ids = g_box[q].dev;
+      *n = g_box[q].n;
+      return BRK_OK;
+    }
+    if (g_box[q].stamp < g_box[victim].stamp) victim = q;
+  }
+  const uint32_t ni = cnt[0], nj = cnt[1], nk = cnt[2], rowlen = ni % 8 ? ni + 1 : ni, rows_per_block = 8;
+  auto id_at = [&](uint32_t k, uint32_t j, uint32_t i) { return base + ((lo[2] + k) * tot[1] + (lo[1] + j)) * tot[0] + lo[0] + i; };
+  std::vector<std::vector<uint32_t>> part(8);
+  const uint32_t jbase = nj / 8, rem = nj % 8;
+  auto push_row = [&](std::vector<uint32_t> &v, uint32_t k, uint32_t j) {
+    for (uint32_t i = 0; i < ni; ++i) v.push_back(id_at(k, j, i));
+    if (rowlen != ni) v.push_back(BRK_LIST_SKIP);
+  };
+  for (uint32_t x = 0; x < 8; ++x) {
+    for (uint32_t j0 = x * jbase; j0 < (x + 1) * jbase; j0 += rows_per_block)
+      for (uint32_t k = 0; k < nk; ++k)
+        for (uint32_t j = j0; j < j0 + rows_per_block && j < (x + 1) * jbase; ++j) push_row(part[x], k, j);
+    if (rem)
+      for (uint32_t k = (uint32_t)((uint64_t)nk * x / 8); k < (uint32_t)((uint64_t)nk * (x + 1) / 8); ++k)
+        for (uint32_t j = nj - rem; j < nj; ++j) push_row(part[x], k, j);
+  }
+  size_t per = 0;
+  for (auto &v : part) per = v.size() > per ? v.size() : per;
+  per = (per + 7) / 8 * 8;
+  std::vector<uint32_t> host(per * 8, BRK_LIST_SKIP);
+  for (uint32_t x = 0; x < 8; ++x) std::copy(part[x].begin(), part[x].end(), host.begin() + x * per);
+  BoxList &e = g_box[victim];
+  if (e.dev) {
+    HIP_TRY(hipDeviceSynchronize()); // a launch still reading the list we are about to replace
+    HIP_TRY(hipFree(e.dev));
+    e.dev = nullptr;
+  }
+  HIP_TRY(hipMalloc(&e.dev, host.size() * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(e.dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  std::memcpy(e.key, key, sizeof key);
+  e.n = (uint32_t)host.size();
+  e.stamp = ++g_box_clock;
+  *ids = e.dev;
+  *n = e.n;
+  return BRK_OK;
+}
+
 extern "C" int brk_stencil_apply_range(int id, const uint32_t *adj, const double *in, double *out, size_t step,
                                        uint32_t begin, uint32_t end, const double *coeff_host, brk_stream s) {
   if (end < begin) return brk_fail(BRK_EINVAL, "brick range [%u,%u) is reversed", begin, end);
@@ -307,13 +374,11 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
   if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7)
     return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s));
-  // other stencils: no arithmetic walk yet -- sweep the box row by row through the range form (rows are contiguous ids)
-  for (uint32_t k = 0; k < cnt[2]; ++k)
-    for (uint32_t j = 0; j < cnt[1]; ++j) {
-      const uint32_t b0 = base + ((lo[2] + k) * tot[1] + (lo[1] + j)) * tot[0] + lo[0];
-      if (int rc = launch_stencil(id, adj, in, out, step, nullptr, b0, cnt[0], coeff_host, s)) return rc;
-    }
-  return BRK_OK;
+  // other stencils: the same traversal order as an id list, built once per box geometry and kept on the device
+  const uint32_t *ids = nullptr;
+  uint32_t n = 0;
+  if (int rc = box_list(base, tot, lo, cnt, &ids, &n)) return rc;
+  return launch_stencil(id, adj, in, out, step, ids, 0, n, coeff_host, s);
 }
 
 extern "C" int brk_link_copy(const brk_link *links, uint32_t n, uint64_t max_bytes, brk_stream s) {

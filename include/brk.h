@@ -81,7 +81,9 @@ int brk_stencil_apply_list(int stencil_id, const uint32_t *adj_dev, const double
  * (i,j,k) in [lo, lo+cnt) (contiguous axis first).  This is exactly the reference launch `dim3 block(NB,NB,NB)` with
  * `b = grid[GB+z][GB+y][GB+x]` over an init_grid numbering (stencils/3axis.hip.cpp:36-39,168-170: base 0, tot = STRIDEB^3,
  * lo = GB, cnt = NB) and the inner region [1,sep0) of a BrickDecomp (base 1, tot = cnt = inner extent, lo = 0).
- * The kernel derives the ids arithmetically in its preferred traversal order; no list is read. */
+ * The 7-point kernels derive the ids arithmetically in their preferred traversal order (no list is read); the other
+ * stencils use an id list in that order which the library builds once per box geometry and keeps on the device (a cache of
+ * 8 geometries per process; the first call for a geometry is synchronous). */
 int brk_stencil_apply_box(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
                           size_t step_elems, uint32_t base, const uint32_t tot_bricks[3], const uint32_t lo[3],
                           const uint32_t cnt[3], const double *coeff_host, brk_stream s);

@@ -382,7 +382,7 @@ def test_full_size_512_properties(oracle, dev, name):
     assert np.abs(got - want.reshape(-1, 512)[sub]).max() <= TOL
 
 
-@pytest.mark.parametrize("name", ["7pt", "mpi7pt", "mpi13pt"])
+@pytest.mark.parametrize("name", ["7pt", "mpi7pt", "mpi13pt", "27pt", "mpi125pt"])
 @pytest.mark.parametrize("shape", [(10, 10, 10), (7, 21, 5), (66, 13, 4)])
 def test_box_form(oracle, dev, name, shape):
     """brk_stencil_apply_box: the reference launch shape (interior box of an init_grid numbering), ids derived in the
@@ -649,3 +649,22 @@ def test_taps_argument_checks(dev):
     for bad in ([((3, 0, 0), 1.0)], [((0, 0, 0), 1.0)] * 126):
         with pytest.raises(BrkError):
             apply_taps(bad, bl.Brick(info, st, 0), bl.Brick(info, so, 0), brick_range=(0, 1))
+
+
+def test_box_list_cache_replacement(oracle, dev):
+    """more box geometries than the library caches id lists for (8): entries are replaced and rebuilt correctly"""
+    shape = (12, 11, 10)
+    grid, info = bl.init_grid(shape, dev)
+    st = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    st.dat.uniform_(0.0, 1.0)
+    hin = st.dat.cpu().numpy()
+    g3 = grid.reshape(shape[2], shape[1], shape[0])
+    boxes = [((1, 1, 1), (3 + q % 5, 2 + q % 4, 1 + q % 3)) for q in range(11)]
+    for rnd in range(2):
+        for lo, cnt in boxes:
+            so = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+            bl.apply_stencil("mpi13pt", bl.Brick(info, st, 0), bl.Brick(info, so, 0), box=(0, shape, lo, cnt))
+            ids = np.ascontiguousarray(g3[lo[2]:lo[2] + cnt[2], lo[1]:lo[1] + cnt[1], lo[0]:lo[0] + cnt[0]]).reshape(-1)
+            want = np.zeros_like(hin)
+            oracle.brick_stencil(NAMES["mpi13pt"], info.adj_host, hin, want, 512, ids=ids)
+            assert np.abs(so.dat.cpu().numpy() - want).max() <= TOL, (rnd, lo, cnt)
