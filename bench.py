@@ -5,8 +5,8 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N = 1  workload "single-7pt-512": the reference's single/hip d3pt7 `Trans` launch (stencils/3axis.hip.cpp:165-171):
-       lexicographic 66^3 brick grid, in/out interleaved in one storage (step 1024), 7pt.py coefficients,
-       one step = one sweep over the 64^3 interior bricks.
+       lexicographic 66^3 brick grid, 7pt.py coefficients, one step = one sweep over the 64^3 interior bricks; input
+       and output fields in two storages (--layout interleaved = one storage as in single/, 1.5 % slower).
 N > 1  workload "weak-mpi7pt-512": weak/main.cu shape: BrickDecomp 512^3 per rank on a periodic MPI_Dims_create(N) grid,
        one step = one brick_func = ghost exchange (per-peer pack -> RCCL send/recv -> unpack, device links for
        self-neighbours) + ST_ITER = 8 sweeps, the exchange hidden behind the part of the sweeps that cannot depend on it
@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = REHEARSAL of the multi-rank control flow with several "
                          "ranks sharing one GPU, ghost bytes staged through host memory (numbers are not a measurement)")
+    ap.add_argument("--layout", default="separate", choices=("separate", "interleaved"),
+                    help="single workload: separate = input and output fields in two storages (step 512, the layout of the "
+                         "reference's weak/strong drivers); interleaved = both fields in one storage (step 1024, the layout of "
+                         "single/: 3axis.cpp:25-28).  Same kernels; interleaving reads and writes in the same DRAM pages costs "
+                         "1.5 % (7-pt) to 10 % (27-pt) on MI355X (profiles/r01_h_layouts.json)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -120,9 +125,14 @@ def run_single(args, bl, dev):
     W = args.warmup if args.warmup is not None else 20
     SB = (N + 16) // 8
     grid, info = bl.init_grid((SB, SB, SB), dev)
-    st = bl.BrickStorage.allocate(info.nbricks, 1024, dev)
+    if args.layout == "interleaved":
+        st = sto = bl.BrickStorage.allocate(info.nbricks, 1024, dev)
+        step_e, off_out = 1024, 512
+    else:
+        st, sto = bl.BrickStorage.allocate(info.nbricks, 512, dev), bl.BrickStorage.allocate(info.nbricks, 512, dev)
+        step_e, off_out = 512, 0
     st.dat.uniform_(0.0, 1.0)
-    bIn, bOut = bl.Brick(info, st, 0), bl.Brick(info, st, 512)
+    bIn, bOut = bl.Brick(info, st, 0), bl.Brick(info, sto, off_out)
     from bricklib_amd.order import tiled
     # same bricks as the reference launch `b = grid[tk][tj][ti]` (3axis.hip.cpp:36-39); only the traversal order is ours
     ids = tiled(grid.reshape(SB, SB, SB)[1:-1, 1:-1, 1:-1])
@@ -147,16 +157,16 @@ def run_single(args, bl, dev):
     wall = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / K
     cells = float(N) ** 3
-    res = {"workload": f"single-{name}-{N}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+    res = {"workload": f"single-{name}-{N}", "layout": args.layout, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
            "kernel": "%s over %d bricks" % ("k_s7_wg<8 waves>" if name in ("7pt", "mpi7pt") else ("k_star" if name in ("mpi13pt", "mpi25pt") else "k_cube"), ids.size)}
     extra = {}
     try:
         from oracle.oracle import Oracle
         O = Oracle()
-        extra["max_abs_err_vs_oracle"] = verify_sample(bl, O, sid, info, st, st, 1024, 512, ids, coeff)
+        extra["max_abs_err_vs_oracle"] = verify_sample(bl, O, sid, info, st, sto, step_e, off_out, ids, coeff)
         if not args.no_cpu_baseline:
-            extra["cpu_baseline"] = cpu_baseline(O, sid, info, st, 1024, ids, coeff, cells, args.cpu_seconds)
+            extra["cpu_baseline"] = cpu_baseline(O, sid, info, st, step_e, ids, coeff, cells, args.cpu_seconds)
     except Exception as e:  # the checker is optional for the measurement itself
         extra["oracle_error"] = repr(e)
     return res, extra
@@ -383,7 +393,7 @@ def main():
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
-                       **{k: res[k] for k in ("cart", "overlap", "exchange", "schedule", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
+                       **{k: res[k] for k in ("layout", "cart", "overlap", "exchange", "schedule", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],

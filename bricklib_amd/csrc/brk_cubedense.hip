@@ -19,6 +19,33 @@
 #include "brk_device.h"
 
 namespace brk {
+#ifdef BRK_STAMP
+// diagnostic build only (make EXTRA_HIPFLAGS=-DBRK_STAMP): per-phase shader-clock totals of k_cube_dense, summed over waves
+constexpr unsigned kStampSlots = 1u << 19;
+__device__ unsigned long long g_stamp[kStampSlots][6]; // one row per list slot: no contention
+#define STAMP(var)                                                                          \
+  unsigned long long var;                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                        \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");              \
+  __builtin_amdgcn_sched_barrier(0)
+extern "C" int brk_debug_stamps(unsigned long long out[8], int reset) {
+  static unsigned long long *host = new unsigned long long[(size_t)kStampSlots * 6];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * kStampSlots * 6) != hipSuccess) return -1;
+  for (int q = 0; q < 8; ++q) out[q] = 0;
+  for (size_t sl = 0; sl < kStampSlots; ++sl)
+    if (host[sl * 6 + 1]) {
+      for (int q = 0; q < 6; ++q) out[q] += host[sl * 6 + q];
+      ++out[7];
+    }
+  if (reset) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamp)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * kStampSlots * 6) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#else
+#define STAMP(var)
+#endif
 namespace {
 
 template <int R>
@@ -107,25 +134,50 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   double *right = tile + roff;
   auto id_of = [&](uint32_t sl) -> uint32_t { return ids ? ids[sl] : first + sl; };
 
+  // The descriptors of the edge/corner gathers depend on the lane only.  They are requested before anything else: a load
+  // issued after the brick's own loads returns after them (vector loads complete in order), and the gathers, which need
+  // the descriptors for their addresses, would wait for a full round trip of the brick before they could even be issued.
+  uint32_t xd[TL::EXTRA_ITERS];
+  {
+    const uint32_t *xt = dense_table<R>();
+#pragma unroll
+    for (int t = 0; t < TL::EXTRA_ITERS; ++t) xd[t] = xt[t * 64 + lane];
+  }
+  STAMP(t0);
   const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;
   const bool active = b != BRK_LIST_SKIP;
   bool link_l = false, link_r = false, brk_l = false;
   double own[8], fkm[R], fkp[R], fjm[R], fjp[R], fim[R], fip[R];
   double xv[TL::EXTRA_ITERS];
-  uint32_t xd[TL::EXTRA_ITERS];
   if (active) {
     const uint32_t b_prev = w > 0 ? __builtin_amdgcn_readfirstlane(id_of(slot - 1)) : BRK_LIST_SKIP;
     const uint32_t b_next = (w + 1 < NW && slot + 1 < n) ? __builtin_amdgcn_readfirstlane(id_of(slot + 1)) : BRK_LIST_SKIP;
     const int l27 = lane < 27 ? lane : 13;
+#ifdef BRK_STAMP
+    asm volatile("" ::"s"(b_prev), "s"(b_next));
+#endif
+    STAMP(t0a);
+    // the three adjacency rows are requested BEFORE the brick itself: vector loads return in order, and everything
+    // below (links, face addresses) waits for the rows -- behind the 4 KiB of the brick that wait is a full HBM round trip
+    // (in-kernel stamps: 8500 of a wave's 15000 cycles went by before the face loads were issued)
     const uint32_t arow = adj[(size_t)b * 27 + l27]; // lanes 0..26: the adjacency row
+    const uint32_t prow = adj[(size_t)(b_prev != BRK_LIST_SKIP ? b_prev : b) * 27 + l27];
+    const uint32_t nrow = adj[(size_t)(b_next != BRK_LIST_SKIP ? b_next : b) * 27 + l27];
+    __builtin_amdgcn_sched_barrier(0);
     const gcptr self = sbase(in + (size_t)b * step);
 #pragma unroll
     for (int k = 0; k < 8; ++k) own[k] = self[k * 64 + lane];
-    const uint32_t prow = adj[(size_t)(b_prev != BRK_LIST_SKIP ? b_prev : b) * 27 + l27];
-    const uint32_t nrow = adj[(size_t)(b_next != BRK_LIST_SKIP ? b_next : b) * 27 + l27];
     link_l = b_prev != BRK_LIST_SKIP && linked(prow, arow, lane);
     link_r = b_next != BRK_LIST_SKIP && linked(arow, nrow, lane);
     brk_l = b_prev != BRK_LIST_SKIP && !link_l; // two active neighbours that cannot share
+    STAMP(t0b);
+#ifdef BRK_STAMP
+    if (lane == 0 && slot < kStampSlots) {
+      g_stamp[slot][0] = t0a - t0;
+      g_stamp[slot][1] = t0b - t0a;
+      g_stamp[slot][2] = t0b; // completed below
+    }
+#endif
     const uint32_t n_im = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, -1));
     const uint32_t n_ip = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, 1));
     const gcptr p_km = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(-1, 0, 0)) * step);
@@ -150,9 +202,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 #pragma unroll
       for (int r = 0; r < R; ++r) fip[r] = p_ip[hi * 64 + lo * 8 + r];
     }
-    const uint32_t *xt = dense_table<R>();
     auto gather = [&](int t) {
-      xd[t] = xt[t * 64 + lane];
       const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((xd[t] >> 16) & 31u) << 2), (int)arow);
       xv[t] = xd[t] != 0xFFFFFFFFu ? in[(size_t)nb * step + ((xd[t] >> 21) & 511u)] : 0.0;
     };
@@ -167,8 +217,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
       for (int t = TL::IT0 + TL::ITS; t < TL::EXTRA_ITERS; ++t) gather(t);
     }
   }
+  STAMP(t1); // everything is requested
+#ifdef BRK_STAMP
+  __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): all loads back
+#endif
+  STAMP(t2);
   if (lane == 0) breaks[w] = brk_l ? 1u : 0u;
   __syncthreads();
+  STAMP(t3); // first barrier passed
   // 2-colouring of the runs: phase of wave w = parity of the breaks at or before it
   const unsigned long long bm = __ballot(lane < NW && breaks[lane < NW ? lane : 0] != 0u);
   const int my_phase = __builtin_popcountll(bm & ((2ull << w) - 1ull)) & 1;
@@ -210,7 +266,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
           if (xd[t] != 0xFFFFFFFFu) right[xd[t] & 0xFFFFu] = xv[t];
       }
     }
+    STAMP(t4); // staged
     __syncthreads(); // the tiles of this phase are complete
+    STAMP(t5);
+#ifdef BRK_STAMP
+    if (lane == 0 && active && ph == 0 && slot < kStampSlots) {
+      g_stamp[slot][2] = t1 - g_stamp[slot][2];
+      g_stamp[slot][3] = t2 - t1;
+      g_stamp[slot][4] = t5 - t2;
+    }
+#endif
     if (mine) {
       // per-lane offset of column lo+di relative to the row start: own tile, or the slot on that side
       int col[2 * R + 1];
@@ -246,6 +311,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
         for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
       }
     }
+    STAMP(t6);
+#ifdef BRK_STAMP
+    if (lane == 0 && active && ph == 0 && slot < kStampSlots) g_stamp[slot][5] = t6 - t5;
+#endif
     if (ph + 1 < nphase) __syncthreads(); // phase 1 overwrites slots phase 0 was reading
   }
 }

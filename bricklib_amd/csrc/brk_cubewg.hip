@@ -28,6 +28,9 @@ __global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : 2)) void k
   double *tile = lds + w * TL::ELEMS;
   auto id_of = [&](uint32_t sl) -> uint32_t { return ids ? ids[sl] : first + sl; };
 
+  uint32_t xd[TL::EXTRA_ITERS]; // gather descriptors first, see cube_stage() in brick-device.h
+#pragma unroll
+  for (int t = 0; t < TL::EXTRA_ITERS; ++t) xd[t] = extra_table<R>()[t * 64 + lane];
   const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;
   const bool active = b != BRK_LIST_SKIP;
   bool share_im = false, share_ip = false;
@@ -66,12 +69,9 @@ __global__ __launch_bounds__(64 * NW, (CubeTraits<KIND>::R == 1 ? 4 : 2)) void k
 #pragma unroll
       for (int r = 0; r < R; ++r) fip[r] = p_ip[hi * 64 + lo * 8 + r];
     }
-    const uint32_t *xt = extra_table<R>();
     double xv[TL::EXTRA_ITERS];
-    uint32_t xd[TL::EXTRA_ITERS];
 #pragma unroll
     for (int t = 0; t < TL::EXTRA_ITERS; ++t) {
-      xd[t] = xt[t * 64 + lane];
       const uint32_t side = xd[t] >> 30; // 0: di = 0, 1: di = -1, 2: di = +1, 3: padding
       const bool live = side == 0 || (side == 1 && !share_im) || (side == 2 && !share_ip);
       const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((xd[t] >> 16) & 31u) << 2), (int)arow);

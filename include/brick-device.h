@@ -328,6 +328,13 @@ __device__ __forceinline__ void cube_stage(double *tile, const uint32_t *__restr
                                            size_t step, uint32_t b, int lane) {
   using TL = CubeTile<R>;
   const int hi = lane >> 3, lo = lane & 7;
+  // The gather descriptors depend on the lane only and are requested first: vector loads return in order, so a table load
+  // issued behind the brick's own loads would come back after them, and the gathers -- which need it for their addresses --
+  // could not even be issued until a full round trip of the brick had passed (in-kernel stamps).
+  const uint32_t *xt = extra_table<R>();
+  uint32_t xd[TL::EXTRA_ITERS];
+#pragma unroll
+  for (int t = 0; t < TL::EXTRA_ITERS; ++t) xd[t] = xt[t * 64 + lane];
   const uint32_t arow = adj[(size_t)b * 27 + (lane < 27 ? lane : 13)];
   const double *self = in + (size_t)b * step;
   const double *p_km = in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(-1, 0, 0)) * step;
@@ -350,12 +357,9 @@ __device__ __forceinline__ void cube_stage(double *tile, const uint32_t *__restr
     fim[r] = p_im[hi * 64 + lo * 8 + (8 - R + r)];
     fip[r] = p_ip[hi * 64 + lo * 8 + r];
   }
-  const uint32_t *xt = extra_table<R>();
   double xv[TL::EXTRA_ITERS];
-  uint32_t xd[TL::EXTRA_ITERS];
 #pragma unroll
   for (int t = 0; t < TL::EXTRA_ITERS; ++t) {
-    xd[t] = xt[t * 64 + lane];
     const bool live = xd[t] != 0xFFFFFFFFu;
     // neighbour id of this lane's cell: pull lane (slot) of the adjacency-row register
     const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((xd[t] >> 16) & 31u) << 2), (int)arow);

@@ -4,6 +4,7 @@
 //         single/ shape: lexicographic (N/8+2)^3 grid, interleaved storage (step 1024), list API over the interior
 //     -r  shuffle the brick list (worst-case locality)
 // Every variant is checked against variant 1 (generic kernel) with a device-side max|a-b|.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -292,6 +293,18 @@ int main(int argc, char **argv) {
       printf("variant %d  %.4f ms  %.1f GStencil/s  %.0f GB/s (%.1f%% of 8 TB/s)  maxdiff_vs_v1 %.3g\n", v, ms,
              cells / ms / 1e6, 16.0 * cells / ms / 1e6, 16.0 * cells / ms / 1e6 / 80.0, md);
       fflush(stdout);
+      // diagnostic builds of libbrk.so (make -C bricklib_amd/csrc EXTRA_HIPFLAGS=-DBRK_STAMP) export per-phase shader-clock
+      // totals of k_cube_dense (in-kernel s_memtime stamps, one row per list slot)
+      typedef int (*stamp_fn)(unsigned long long *, int);
+      static stamp_fn stamps = (stamp_fn)dlsym(RTLD_DEFAULT, "brk_debug_stamps");
+      if (stamps) {
+        unsigned long long t[8];
+        if (stamps(t, 1) == 0 && t[7]) {
+          const double w = (double)t[7];
+          printf("   stamps per wave (clk): ids %.0f | rows+links %.0f | issue faces+gathers %.0f | loads back %.0f | barriers+stage %.0f | compute+store %.0f  (%llu waves)\n",
+                 t[0] / w, t[1] / w, t[2] / w, t[3] / w, t[4] / w, t[5] / w, t[7]);
+        }
+      }
     }
   return 0;
 }
