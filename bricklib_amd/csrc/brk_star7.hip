@@ -179,6 +179,34 @@ __device__ __forceinline__ bool box_entry(const Box &bx, uint32_t x, uint32_t g,
   return true;
 }
 
+#ifdef BRK_STAMP_S7
+// diagnostic build only (make EXTRA_HIPFLAGS=-DBRK_STAMP_S7): s_memtime at the phase boundaries of k_s7_wg, one row per slot
+} // namespace
+constexpr unsigned kStampSlots7 = 1u << 19;
+__device__ unsigned long long g_stamp7[kStampSlots7][6];
+#define STAMP7(var)                                                            \
+  unsigned long long var;                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+extern "C" int brk_debug_stamps(unsigned long long out[8], int reset) {
+  static unsigned long long *host = new unsigned long long[(size_t)kStampSlots7 * 6];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp7), sizeof(unsigned long long) * kStampSlots7 * 6) != hipSuccess) return -1;
+  for (int q = 0; q < 8; ++q) out[q] = 0;
+  for (size_t sl = 0; sl < kStampSlots7; ++sl)
+    if (host[sl * 6 + 1]) {
+      for (int q = 0; q < 6; ++q) out[q] += host[sl * 6 + q];
+      ++out[7];
+    }
+  void *p = nullptr;
+  if (reset && (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stamp7)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * kStampSlots7 * 6) != hipSuccess)) return -1;
+  return 0;
+}
+namespace {
+#else
+#define STAMP7(var)
+#endif
+
 template <int MPI, int NW, int MODE>
 __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uint32_t *__restrict__ adj,
                                                                       const double *__restrict__ in,
@@ -197,6 +225,7 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
   // load is kept short: the brick id and its two list neighbours come from three clamped scalar loads issued together
   // (no branches), the adjacency row is requested next, and the 8 loads of the brick itself -- which need only the id --
   // are issued before the adjacency row is waited for.
+  STAMP7(t0);
   uint32_t b = 0, b_prev, b_next;
   bool active, has_prev = w > 0, has_next = w + 1 < NW && slot + 1 < n;
   if (MODE == kModeBox) {
@@ -221,6 +250,10 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
   }
   Faces f;
   bool share_im = false, share_ip = false;
+#ifdef BRK_STAMP_S7
+  asm volatile("" ::"s"(b), "s"(b_prev), "s"(b_next));
+#endif
+  STAMP7(t1); // ids known
   if (active) {
     const Nbr nb = load_nbr(adj, b);
     const gcptr self = sbase(in + (size_t)b * step);
@@ -234,6 +267,14 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
     const gcptr p_kp = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.kp) * step);
     const gcptr p_jm = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.jm) * step);
     const gcptr p_jp = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.jp) * step);
+    STAMP7(t2); // adjacency known (own loads in flight)
+#ifdef BRK_STAMP_S7
+    if (lane == 0 && slot < kStampSlots7) {
+      g_stamp7[slot][0] = t1 - t0;
+      g_stamp7[slot][1] = t2 - t1;
+      g_stamp7[slot][2] = t2;
+    }
+#endif
     f.km = p_km[7 * 64 + lane];
     f.kp = p_kp[lane];
     f.jm = p_jm[hi * 64 + 7 * 8 + lo];
@@ -242,10 +283,21 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
     f.ip = 0.0;
     if (!share_im) f.im = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.im) * step)[hi * 64 + lo * 8 + 7];
     if (!share_ip) f.ip = sbase(in + (size_t)__builtin_amdgcn_readfirstlane(nb.ip) * step)[hi * 64 + lo * 8];
+    STAMP7(t3); // everything requested
+#ifdef BRK_STAMP_S7
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    STAMP7(t4);
+    if (lane == 0 && slot < kStampSlots7) {
+      g_stamp7[slot][2] = t3 - g_stamp7[slot][2];
+      g_stamp7[slot][3] = t4 - t3;
+      g_stamp7[slot][4] = t4;
+    }
+#endif
     stage(tile, f, lane);
   }
   __syncthreads(); // every wave's brick is staged; sibling tiles are now readable
   if (!active) return;
+  STAMP7(t5);
   gptr dst = (gptr)(out + (size_t)b * step);
   asm volatile("" : "+s"(dst)); // see sbase()
   const int o_jm = hi * 8 + lo, o_jp = (hi + 2) * 8 + lo;
@@ -262,6 +314,13 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
     res = point7<MPI>(kp, km, jp, jm, ip, im, c0, cf);
     store_result(&dst[k * 64 + lane], res);
   }
+  STAMP7(t6);
+#ifdef BRK_STAMP_S7
+  if (lane == 0 && slot < kStampSlots7) {
+    g_stamp7[slot][4] = t5 - g_stamp7[slot][4];
+    g_stamp7[slot][5] = t6 - t5;
+  }
+#endif
 }
 
 } // namespace

@@ -301,7 +301,7 @@ int main(int argc, char **argv) {
         unsigned long long t[8];
         if (stamps(t, 1) == 0 && t[7]) {
           const double w = (double)t[7];
-          printf("   stamps per wave (clk): ids %.0f | rows+links %.0f | issue faces+gathers %.0f | loads back %.0f | barriers+stage %.0f | compute+store %.0f  (%llu waves)\n",
+          printf("   stamps per wave (clk): ids %.0f | adjacency %.0f | issue faces+gathers %.0f | loads back %.0f | stage+barriers %.0f | compute+store %.0f  (%llu waves)\n",
                  t[0] / w, t[1] / w, t[2] / w, t[3] / w, t[4] / w, t[5] / w, t[7]);
         }
       }
