@@ -41,6 +41,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
   const bool active = b != BRK_LIST_SKIP;
   bool share_im = false, share_ip = false;
   if (active) {
+    // the brick's own planes need only its id: they are in flight before the adjacency row is even requested (scalar loads
+    // return out of order, so every wait on them is lgkmcnt(0) -- anything issued behind such a wait starts a round trip late)
+    const gcptr self = sbase(in + (size_t)b * step);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col[R + k] = self[k * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
     const uint32_t *row = adj + (size_t)b * 27;
     const uint32_t n_km = __builtin_amdgcn_readfirstlane(row[adj_slot(-1, 0, 0)]);
     const uint32_t n_kp = __builtin_amdgcn_readfirstlane(row[adj_slot(1, 0, 0)]);
@@ -52,12 +58,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     const uint32_t b_next = (w + 1 < NW && slot + 1 < n) ? __builtin_amdgcn_readfirstlane(id_of(slot + 1)) : 0xFFFFFFFFu;
     share_im = n_im == b_prev;
     share_ip = n_ip == b_next;
-    const gcptr self = sbase(in + (size_t)b * step);
     const gcptr p_km = sbase(in + (size_t)n_km * step), p_kp = sbase(in + (size_t)n_kp * step);
     const gcptr p_jm = sbase(in + (size_t)n_jm * step), p_jp = sbase(in + (size_t)n_jp * step);
-    // ---- all loads first
-#pragma unroll
-    for (int k = 0; k < 8; ++k) col[R + k] = self[k * 64 + lane];
     double fjm[R], fjp[R], fim[R], fip[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
