@@ -113,7 +113,7 @@ __device__ __forceinline__ bool linked(uint32_t rl, uint32_t rr, int lane) {
   return __ballot(!ok) == 0ull;
 }
 
-template <int KIND, int NW, int OCC, bool PIPE = true>
+template <int KIND, int NW, int OCC, int PIPE = 1>
 __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
     const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
@@ -286,7 +286,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
       }
       if (KIND == kCube125) {
         const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
-        if (PIPE) cube125_accumulate<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
+        if (PIPE == 1) cube125_accumulate<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
+        else if (PIPE == 2) cube125_accumulate_static<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
         else cube125_accumulate_simple<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
       } else {
         double acc[8];
@@ -321,8 +322,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 
 } // namespace
 
-// variants: 27-pt 0/6 = NW 4 (default), 5 = NW 8; 125-pt 0/5 = NW 4, 3 waves/SIMD, plain plane loop (default),
-// 6 = NW 4 and 7 = NW 8 with the software-pipelined plane loop (2 waves/SIMD)
+// variants: 27-pt 0/6 = NW 4 (default), 5 = NW 8; 125-pt 0/5 = NW 4, 3 waves/SIMD, fully unrolled plane loop with static
+// accumulators (default), 9 = the same with the rolled loop over a ring, 6 = NW 4 and 7 = NW 8 with the software-pipelined
+// rolled loop (2 waves/SIMD)
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8, wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
@@ -335,8 +337,10 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 2>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 7) {
     hipLaunchKernelGGL((k_cube_dense<kCube125, 8, 2>), dim3(wgs8), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (variant == 9) {
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 0>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   } else {
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, false>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 2>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;

@@ -199,10 +199,10 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   // 27/125-pt: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip) by default; variant 1 = generic
   // one-wave kernel, 27-pt variant 2 and 125-pt variants 2/4/8 = padded tiles with shared i-halos (brk_cubewg.hip),
   // 125-pt variant 3 = generic kernel with 4 waves per workgroup.  Measured at 512^3 (profiles/): 27-pt 0.555 (padded,
-  // 8 waves) -> 0.484 ms; 125-pt 1.06 (generic) -> 0.845 ms.
+  // 8 waves) -> 0.43 ms; 125-pt 1.06 (generic) -> 0.70 ms.
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = g_variant[id];
-    if (v == 0 || (v >= 5 && v <= 7)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st);
+    if (v == 0 || (v >= 5 && v <= 9)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st);
     if ((id == BRK_27PT_COEFF && v == 2) || (id == BRK_MPI125 && (v == 2 || v == 4 || v == 8)))
       return launch_cube_wg(id, id == BRK_MPI125 ? v : 8, adj, in, out, step, ids, first, n, cf, st);
   }

@@ -320,6 +320,55 @@ __device__ __forceinline__ void cube125_accumulate_simple(const double *rowp, co
   }
 }
 
+// Fully unrolled plane loop with one scheduling fence per plane: the ring becomes eight statically named accumulators
+// (no register rotation: 17 moves per plane less), the 25 reads of a plane take immediate offsets from five per-lane column
+// bases (no per-plane address adds), and the validity tests of the outputs are compile-time.  The fences keep hipcc from
+// hoisting the reads of all planes (which costs 256 VGPRs + scratch, see above); one plane's 25 values are live at a time.
+template <int PS, int RS>
+__device__ __forceinline__ void cube125_accumulate_static(const double *rowp, const int (&co)[5], const Coeffs &cf,
+                                                          double *dst, int lane) {
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+  const double *colp[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) colp[d] = rowp + co[d];
+#pragma unroll
+  for (int kk = 0; kk < 12; ++kk) {
+    double u[3][3];
+#pragma unroll
+    for (int dj = 0; dj < 5; ++dj) {
+      const double v0 = colp[0][kk * PS + (dj - 2) * RS], v1 = colp[1][kk * PS + (dj - 2) * RS];
+      const double v2 = colp[2][kk * PS + (dj - 2) * RS], v3 = colp[3][kk * PS + (dj - 2) * RS];
+      const double v4 = colp[4][kk * PS + (dj - 2) * RS];
+      const double s0 = v2, s1 = v1 + v3, s2 = v0 + v4;
+      const int bcls = dj < 2 ? 2 - dj : dj - 2;
+      if (dj <= 2) {
+        u[0][bcls] = s0;
+        u[1][bcls] = s1;
+        u[2][bcls] = s2;
+      } else {
+        u[0][bcls] += s0;
+        u[1][bcls] += s1;
+        u[2][bcls] += s2;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const int k = kk - 4 + m; // output fed through |dk| = |2 - m|
+      if (k >= 0 && k < 8) {
+        const int c = m < 2 ? 2 - m : m - 2;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) acc[k] += cf.c[cls125(c, bb, a)] * u[a][bb];
+      }
+    }
+    if (kk >= 4) store_result(&dst[(kk - 4) * 64 + lane], acc[kk - 4]); // output kk-4 has received its last plane
+    __builtin_amdgcn_sched_barrier(0); // a fence every second plane instead: 140 VGPRs and 1.08 instead of 0.70 ms
+  }
+}
+
 // Load brick `b` (wave-uniform) with its full halo of radius R into `tile` (this wave's private LDS slice of
 // CubeTile<R>::ELEMS doubles): own brick and the 6 faces by structured coalesced loads, edge/corner cells through the
 // descriptor table.
