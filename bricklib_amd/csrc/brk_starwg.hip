@@ -20,6 +20,34 @@ struct WgTile {
   static constexpr int TILE = 8 * PLANE;
 };
 
+#ifdef BRK_STAMP_SW
+// diagnostic build only (make EXTRA_HIPFLAGS=-DBRK_STAMP_SW): s_memtime at the phase boundaries of k_star_wg, one row per slot
+} // namespace
+constexpr unsigned kStampSlotsW = 1u << 19;
+__device__ unsigned long long g_stampw[kStampSlotsW][6];
+#define STAMPW(var)                                                            \
+  unsigned long long var;                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                           \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+extern "C" int brk_debug_stamps(unsigned long long out[8], int reset) {
+  static unsigned long long *host = new unsigned long long[(size_t)kStampSlotsW * 6];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stampw), sizeof(unsigned long long) * kStampSlotsW * 6) != hipSuccess) return -1;
+  for (int q = 0; q < 8; ++q) out[q] = 0;
+  for (size_t sl = 0; sl < kStampSlotsW; ++sl)
+    if (host[sl * 6 + 1]) {
+      for (int q = 0; q < 6; ++q) out[q] += host[sl * 6 + q];
+      ++out[7];
+    }
+  void *p = nullptr;
+  if (reset && (hipGetSymbolAddress(&p, HIP_SYMBOL(g_stampw)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned long long) * kStampSlotsW * 6) != hipSuccess)) return -1;
+  return 0;
+}
+namespace {
+#else
+#define STAMPW(var)
+#endif
+
 template <int KIND, int NW, int OCC>
 __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
@@ -37,8 +65,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
   auto id_of = [&](uint32_t sl) -> uint32_t { return ids ? ids[sl] : first + sl; };
 
   double col[8 + 2 * R];
+  STAMPW(t0);
   const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;
   const bool active = b != BRK_LIST_SKIP;
+#ifdef BRK_STAMP_SW
+  asm volatile("" ::"s"(b));
+#endif
+  STAMPW(t1); // id known
   bool share_im = false, share_ip = false;
   if (active) {
     // the brick's own planes need only its id: they are in flight before the adjacency row is even requested (scalar loads
@@ -58,6 +91,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     const uint32_t b_next = (w + 1 < NW && slot + 1 < n) ? __builtin_amdgcn_readfirstlane(id_of(slot + 1)) : 0xFFFFFFFFu;
     share_im = n_im == b_prev;
     share_ip = n_ip == b_next;
+    STAMPW(t2); // adjacency + list neighbours known (own planes in flight)
     const gcptr p_km = sbase(in + (size_t)n_km * step), p_kp = sbase(in + (size_t)n_kp * step);
     const gcptr p_jm = sbase(in + (size_t)n_jm * step), p_jp = sbase(in + (size_t)n_jp * step);
     double fjm[R], fjp[R], fim[R], fip[R];
@@ -79,6 +113,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
 #pragma unroll
       for (int r = 0; r < R; ++r) fip[r] = p_ip[hi * 64 + lo * 8 + r];
     }
+    STAMPW(t3); // everything requested
+#ifdef BRK_STAMP_SW
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    STAMPW(t4);
+    if (lane == 0 && slot < kStampSlotsW) {
+      g_stampw[slot][0] = t1 - t0;
+      g_stampw[slot][1] = t2 - t1;
+      g_stampw[slot][2] = t3 - t2;
+      g_stampw[slot][3] = t4 - t3;
+      g_stampw[slot][4] = t4;
+    }
+#endif
     // ---- stage
 #pragma unroll
     for (int k = 0; k < 8; ++k) tile[k * TL::PLANE + (hi + R) * 8 + lo] = col[R + k];
@@ -98,6 +144,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
   }
   __syncthreads(); // sibling tiles are readable
   if (!active) return;
+  STAMPW(t5);
   gptr dst = (gptr)(out + (size_t)b * step);
   asm volatile("" : "+s"(dst));
   // per-lane plane-0 offsets of the 2R i-neighbours: own tile, sibling tile (one tile to the left/right, same bank as
@@ -129,6 +176,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     res = res + col[R + k] * cf.c[0];
     store_result(&dst[k * 64 + lane], res);
   }
+  STAMPW(t6);
+#ifdef BRK_STAMP_SW
+  if (lane == 0 && slot < kStampSlotsW) {
+    g_stampw[slot][4] = t5 - g_stampw[slot][4];
+    g_stampw[slot][5] = t6 - t5;
+  }
+#endif
 }
 
 } // namespace

@@ -28,7 +28,11 @@ __host__ __device__ constexpr int adj_slot(int dk, int dj, int di) { return (dk 
 // Measured on the 512^3 7-point sweep: 0.402 -> 0.379 ms (profiles/).
 template <class P>
 __device__ __forceinline__ void store_result(P *p, double v) {
+#ifdef BRK_PLAIN_STORE
+  *p = v;
+#else
   __builtin_nontemporal_store(v, p);
+#endif
 }
 
 // Wave-local LDS ordering.  The hardware runs one wave's DS instructions in order; these only stop the
