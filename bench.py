@@ -63,6 +63,9 @@ def parse():
                          "reference's weak/strong drivers); interleaved = both fields in one storage (step 1024, the layout of "
                          "single/: 3axis.cpp:25-28).  Same kernels; interleaving reads and writes in the same DRAM pages costs "
                          "1.5 % (7-pt) to 10 % (27-pt) on MI355X (profiles/r01_h_layouts.json)")
+    ap.add_argument("--emulate-exchange-ms", type=float, default=0.0,
+                    help="EXPERIMENT (one-GPU boxes): add a spin kernel of this length to every exchange, on the exchange's "
+                         "stream, to see how much exchange time each schedule hides; results are not a measurement of any link")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -190,6 +193,22 @@ def run_weak(args, bl, dev, rank, world):
     stA.dat.uniform_(0.0, 1.0)
     A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
     ex = Exchanger(d, stA, rank, mode=args.exchange, staged=args.backend == "gloo")
+    if args.emulate_exchange_ms > 0:
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # calibrate torch.cuda._sleep
+        torch.cuda._sleep(1000000)
+        c0.record()
+        torch.cuda._sleep(4000000)
+        c1.record()
+        torch.cuda.synchronize()
+        spin = int(args.emulate_exchange_ms / (c0.elapsed_time(c1) / 4000000))
+        real_exchange = ex.exchange
+
+        def slow_exchange(stream=None):
+            real_exchange(stream)
+            with torch.cuda.stream(stream or torch.cuda.current_stream()):
+                torch.cuda._sleep(spin)
+
+        ex.exchange = slow_exchange
     from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
     S = bl.stencil_iters(sid)
     sweep_ms = None
