@@ -63,6 +63,8 @@ def parse():
                          "reference's weak/strong drivers); interleaved = both fields in one storage (step 1024, the layout of "
                          "single/: 3axis.cpp:25-28).  Same kernels; interleaving reads and writes in the same DRAM pages costs "
                          "1.5 % (7-pt) to 10 % (27-pt) on MI355X (profiles/r01_h_layouts.json)")
+    ap.add_argument("--deep-depth", type=int, default=0,
+                    help="--schedule deep: split only the first K sweeps into early/late passes (0 = all ST_ITER sweeps)")
     ap.add_argument("--emulate-exchange-ms", type=float, default=0.0,
                     help="EXPERIMENT (one-GPU boxes): add a spin kernel of this length to every exchange, on the exchange's "
                          "stream, to see how much exchange time each schedule hides; results are not a measurement of any link")
@@ -226,6 +228,7 @@ def run_weak(args, bl, dev, rank, world):
     main = torch.cuda.current_stream()
     comm = torch.cuda.Stream()
     schedule = "plain" if args.no_overlap else args.schedule
+    deep_depth = args.deep_depth
     probe_ms = None
     if schedule == "auto":
         # measure, don't guess: the exchange alone (max over ranks) ...
@@ -256,16 +259,22 @@ def run_weak(args, bl, dev, rank, world):
             dist.all_reduce(x, op=dist.ReduceOp.MAX)
         probe_ms, sweep_ms = float(x[0].item()), float(x[1].item())
         T = S * sweep_ms
-        cost = {"plain": T + probe_ms, "surface": 1.045 * T + max(0.0, 1.3 * probe_ms - 0.21 * T),
-                "deep": 1.09 * T + max(0.0, 1.3 * probe_ms - 0.59 * T)}
-        schedule = min(cost, key=cost.get)
+        tb = [d.t_dims[a] for a in range(3)]
+        share = [max(0, (tb[0] - 2 * (t + 1))) * max(0, (tb[1] - 2 * (t + 1))) * max(0, (tb[2] - 2 * (t + 1))) / float(tb[0] * tb[1] * tb[2])
+                 for t in range(1, S + 1)]                       # part of sweep t that can run before the ghosts land
+        cost = {("plain", 0): T + probe_ms, ("surface", 0): 1.03 * T + max(0.0, 1.2 * probe_ms - 0.2 * T)}
+        for k in range(2, S + 1):                               # deep with k split sweeps: +0.8 % per level, measured at k = 8
+            cost[("deep", k)] = (1.0 + 0.008 * k) * T + max(0.0, 1.2 * probe_ms - sum(share[:k]) * sweep_ms)
+        schedule, deep_depth = min(cost, key=cost.get)
     overlap = schedule != "plain"
     state = {}
     if schedule == "deep":
         lists = TrapezoidLists(d, S, dev)
+        whole = SweepLists(d, dev)
+        deep_depth = S if not deep_depth else max(1, min(deep_depth, S))
 
         def step():
-            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=comm)
+            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=comm, depth=deep_depth, full=whole)
     else:
         lists = SweepLists(d, dev)
 
@@ -310,7 +319,7 @@ def run_weak(args, bl, dev, rank, world):
     res = {"workload": f"weak-{name}-{N}", "conservation_rel_drift": drift, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,
            "kernel": "%s sweeps over brick lists of BrickDecomp(%d^3): %d sweeps + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S),
-           "cart": cart, "overlap": overlap, "exchange": args.exchange, "schedule": schedule, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
+           "cart": cart, "overlap": overlap, "exchange": args.exchange, "schedule": schedule, "deep_depth": deep_depth if schedule == "deep" else None, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
            "remote_bytes_per_rank": ex.bytes_remote}
     return res, {}
 
@@ -412,7 +421,7 @@ def main():
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
-                       **{k: res[k] for k in ("layout", "cart", "overlap", "exchange", "schedule", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
+                       **{k: res[k] for k in ("layout", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],

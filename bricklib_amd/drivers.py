@@ -80,16 +80,21 @@ class TrapezoidLists:
         self.shell = [grid_to_device(x, device) if x.size else None for x in shell]
 
 
-def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, comm=None):
+def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, comm=None, depth=None, full=None):
     """Same result as weak_cycle, scheduled so that the exchange hides behind most of the cycle instead of one sweep
     (xGMI is a per-link-bound point-to-point fabric; a 512^3 subdomain sends 104 MB per exchange).  While the ghosts
     of A travel on `comm`, `main` runs the part of EVERY sweep that cannot depend on them yet -- sweep t over the bricks
     at least t+1 bricks inside the ghosted grid (a shrinking box, 59 % of all brick updates at 512^3 / 8 sweeps) -- and
     afterwards the remaining shells of sweeps 1..S in order.  Ping-pong safety: the early pass of sweep t+2 overwrites
     the source of sweep t+1 only at depth >= t+3, while the late pass of sweep t+1 reads depth <= t+2.
-    lists: TrapezoidLists(d, stencil_iters(stencil))."""
+    lists: TrapezoidLists(d, stencil_iters(stencil)).
+    depth (1..S, default S): only the first `depth` sweeps are split this way (2*depth launches, hiding the early passes
+    of those sweeps); the remaining sweeps run whole over full.all / full.domain (full: SweepLists(d)).  A shallower
+    schedule hides less exchange time and costs fewer, larger launches."""
     S = stencil_iters(stencil)
     assert len(lists.inner) == S
+    K = S if depth is None else max(1, min(int(depth), S))
+    assert K == S or full is not None, "depth < ST_ITER needs the whole-sweep lists (full=SweepLists(d))"
     main = main or torch.cuda.current_stream()
     if comm is None:
         exchange(main)
@@ -102,10 +107,13 @@ def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, co
         ev1.record(comm)
     for ids in (lists.inner, lists.shell):
         src, dst = A, B
-        for t in range(S):
+        for t in range(K):
             if ids[t] is not None:
                 apply_stencil(stencil, src, dst, ids=ids[t], coeff=coeff, stream=main)
             src, dst = dst, src
         if comm is not None and ids is lists.inner:
             main.wait_event(ev1)
+    for t in range(K, S):   # sweeps K+1..S whole; src/dst continue the ping-pong (sweep t+1 reads what sweep t wrote)
+        apply_stencil(stencil, src, dst, ids=full.domain if t == S - 1 else full.all, coeff=coeff, stream=main)
+        src, dst = dst, src
     return S

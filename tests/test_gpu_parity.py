@@ -428,7 +428,7 @@ def test_weak_cycle_overlap_streams_single_rank(oracle, dev):
     bl.populate(d, [1, 1, 1], [0, 0, 0])
     info = d.getBrickInfo(dev)
     res = []
-    for mode in ("plain", "overlap", "deep"):
+    for mode in ("plain", "overlap", "deep", "deep3"):
         torch.manual_seed(3)
         stA, stB = info.allocate(512, dev), info.allocate(512, dev)
         stA.dat.uniform_(0.0, 1.0)
@@ -441,11 +441,13 @@ def test_weak_cycle_overlap_streams_single_rank(oracle, dev):
                 weak_cycle("mpi7pt", d, A, B, ex.exchange, lists=lists)
             elif mode == "deep":
                 weak_cycle_deep("mpi7pt", d, A, B, ex.exchange, deep, main=main, comm=comm)
+            elif mode == "deep3":
+                weak_cycle_deep("mpi7pt", d, A, B, ex.exchange, deep, main=main, comm=comm, depth=3, full=lists)
             else:
                 weak_cycle("mpi7pt", d, A, B, ex.exchange, main=main, comm=comm, overlap=True, lists=lists, state=state)
         torch.cuda.synchronize()
         res.append(stA.dat[512 * 1:512 * d.sep_pos[1]].clone())
-    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    assert all(torch.equal(res[0], r) for r in res[1:])
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2])
