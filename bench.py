@@ -262,9 +262,11 @@ def run_weak(args, bl, dev, rank, world):
         tb = [d.t_dims[a] for a in range(3)]
         share = [max(0, (tb[0] - 2 * (t + 1))) * max(0, (tb[1] - 2 * (t + 1))) * max(0, (tb[2] - 2 * (t + 1))) / float(tb[0] * tb[1] * tb[2])
                  for t in range(1, S + 1)]                       # part of sweep t that can run before the ghosts land
-        cost = {("plain", 0): T + probe_ms, ("surface", 0): 1.03 * T + max(0.0, 1.2 * probe_ms - 0.2 * T)}
+        # while it overlaps with sweeps the exchange is taken to progress 1.2x slower (shared HBM): a window of h ms of
+        # independent compute retires h / 1.2 ms of exchange
+        cost = {("plain", 0): T + probe_ms, ("surface", 0): 1.03 * T + max(0.0, probe_ms - 0.2 * T / 1.2)}
         for k in range(2, S + 1):                               # deep with k split sweeps: +0.8 % per level, measured at k = 8
-            cost[("deep", k)] = (1.0 + 0.008 * k) * T + max(0.0, 1.2 * probe_ms - sum(share[:k]) * sweep_ms)
+            cost[("deep", k)] = (1.0 + 0.008 * k) * T + max(0.0, probe_ms - sum(share[:k]) * sweep_ms / 1.2)
         schedule, deep_depth = min(cost, key=cost.get)
     overlap = schedule != "plain"
     state = {}

@@ -4,7 +4,7 @@
 set -o pipefail
 mkdir -p gpurun_out/rehearse
 port=29520
-for cfg in "2 plain" "2 surface" "2 deep" "4 deep" "4 surface"; do   # at most 4 ranks: a one-GPU test box allows 6 processes on the card, launcher included
+for cfg in "2 plain" "2 surface" "2 deep" "2 auto" "4 deep" "4 surface" "4 auto"; do   # at most 4 ranks: a one-GPU test box allows 6 processes on the card, launcher included
   set -- $cfg
   port=$((port + 1))
   out=gpurun_out/rehearse/n$1_$2
