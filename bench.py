@@ -58,6 +58,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = REHEARSAL of the multi-rank control flow with several "
                          "ranks sharing one GPU, ghost bytes staged through host memory (numbers are not a measurement)")
+    ap.add_argument("--form", default="box", choices=("box", "list"),
+                    help="single workload: box = brk_stencil_apply_box over the interior of the init_grid numbering (the "
+                         "reference's launch shape; the 7-point kernels derive the ids arithmetically), list = "
+                         "brk_stencil_apply_list over the same bricks in the same order")
     ap.add_argument("--layout", default="separate", choices=("separate", "interleaved"),
                     help="single workload: separate = input and output fields in two storages (step 512, the layout of the "
                          "reference's weak/strong drivers); interleaved = both fields in one storage (step 1024, the layout of "
@@ -146,8 +150,14 @@ def run_single(args, bl, dev):
     coeff = rng.random(129) if name in ("7pt", "27pt") else None
     stream = torch.cuda.current_stream()
 
+    NB = SB - 2
+    box = (0, (SB, SB, SB), (1, 1, 1), (NB, NB, NB))     # the reference launch: dim3 block(NB,NB,NB), b = grid[GB+z][GB+y][GB+x]
+
     def step():
-        bl.apply_stencil(sid, bIn, bOut, ids=ids_dev, coeff=coeff, stream=stream)
+        if args.form == "box":
+            bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream)
+        else:
+            bl.apply_stencil(sid, bIn, bOut, ids=ids_dev, coeff=coeff, stream=stream)
 
     for _ in range(W):
         step()
@@ -162,7 +172,7 @@ def run_single(args, bl, dev):
     wall = time.perf_counter() - t0
     kern_ms = e0.elapsed_time(e1) / K
     cells = float(N) ** 3
-    res = {"workload": f"single-{name}-{N}", "layout": args.layout, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+    res = {"workload": f"single-{name}-{N}", "layout": args.layout, "form": args.form, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
            "kernel": "%s over %d bricks" % ("k_s7_wg<8 waves>" if name in ("7pt", "mpi7pt") else ("k_star" if name in ("mpi13pt", "mpi25pt") else "k_cube"), ids.size)}
     extra = {}
@@ -423,7 +433,7 @@ def main():
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
-                       **{k: res[k] for k in ("layout", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
+                       **{k: res[k] for k in ("layout", "form", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],
