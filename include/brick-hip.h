@@ -1,29 +1,36 @@
-// brick-hip.h -- HIP names for the gpu* aliases used by brick-gpu.h and the drivers (reference include/brick-hip.h:12-26),
-// plus the device side of the stencils (brick-device.h) which replaces dev_shl.h + generated code.
-#ifndef BRICK_BRICK_HIP_H
-#define BRICK_BRICK_HIP_H
+// brick-hip.h -- the vendor-neutral gpu* names that brick-gpu.h and the drivers use, bound to the HIP runtime.
+// The reference binds them with one macro per name (include/brick-hip.h:12-26); here they are typed inline functions and
+// constants, so a wrong argument is a compile error at the call site instead of inside a macro expansion.  Also pulls in
+// the device side of the stencils (brick-device.h), which takes the place of dev_shl.h + generated code.
+#pragma once
 
 #include <hip/hip_runtime.h>
 
-#define gpuMalloc(p, s) hipMalloc(p, s)
-#define gpuMemcpy(d, p, s, k) hipMemcpy(d, p, s, k)
-#define gpuFree(p) hipFree(p)
-#define gpuGetErrorString(e) hipGetErrorString(e)
-#define gpuDeviceSynchronize() hipDeviceSynchronize()
-#define gpuMemcpyToSymbol(p, d, s) hipMemcpyToSymbol(p, d, s, 0, hipMemcpyHostToDevice)
-#define gpuDeviceSetCacheConfig(c) hipDeviceSetCacheConfig(c)
+#include <cstddef>
 
-#define gpuFuncCachePreferL1 hipFuncCachePreferL1
-#define gpuSuccess hipSuccess
-#define gpuMemcpyKind hipMemcpyKind
-#define gpuMemcpyHostToDevice hipMemcpyHostToDevice
-#define gpuMemcpyDeviceToHost hipMemcpyDeviceToHost
+using gpuMemcpyKind = hipMemcpyKind;
+constexpr hipError_t gpuSuccess = hipSuccess;
+constexpr gpuMemcpyKind gpuMemcpyHostToDevice = hipMemcpyHostToDevice;
+constexpr gpuMemcpyKind gpuMemcpyDeviceToHost = hipMemcpyDeviceToHost;
+constexpr hipFuncCache_t gpuFuncCachePreferL1 = hipFuncCachePreferL1;
 
-#define gpuExecKernel(f, b, t, a...) hipLaunchKernelGGL(f, b, t, 0, 0, a)
+template <class T>
+inline hipError_t gpuMalloc(T **ptr, std::size_t bytes) {
+  return hipMalloc(reinterpret_cast<void **>(ptr), bytes);
+}
+inline hipError_t gpuFree(void *ptr) { return hipFree(ptr); }
+inline hipError_t gpuMemcpy(void *dst, const void *src, std::size_t bytes, gpuMemcpyKind kind) {
+  return hipMemcpy(dst, src, bytes, kind);
+}
+inline const char *gpuGetErrorString(hipError_t e) { return hipGetErrorString(e); }
+inline hipError_t gpuDeviceSynchronize() { return hipDeviceSynchronize(); }
+inline hipError_t gpuDeviceSetCacheConfig(hipFuncCache_t c) { return hipDeviceSetCacheConfig(c); }
+
+// these two take a symbol / a kernel name, so they stay macros
+#define gpuMemcpyToSymbol(symbol, src, bytes) hipMemcpyToSymbol(HIP_SYMBOL(symbol), src, bytes, 0, hipMemcpyHostToDevice)
+#define gpuExecKernel(kernel, blocks, threads, ...) hipLaunchKernelGGL(kernel, blocks, threads, 0, 0, __VA_ARGS__)
 
 #include "brick-gpu.h"
 #if defined(__HIP__)
 #include "brick-device.h"
 #endif
-
-#endif // BRICK_BRICK_HIP_H
