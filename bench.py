@@ -52,9 +52,10 @@ def parse():
     ap.add_argument("--schedule", default="auto", choices=("auto", "deep", "surface", "plain"),
                     help="weak workload: deep = exchange hidden behind the early passes of all sweeps, surface = behind "
                          "the inner bricks of one sweep, plain = in order, auto = cheapest of the three for the measured exchange time")
-    ap.add_argument("--exchange", default="packed", choices=("packed", "direct"),
+    ap.add_argument("--exchange", default="packed", choices=("packed", "direct", "shift"),
                     help="weak workload, runs that leave the GPU: packed = one RCCL send+recv per peer through pack/unpack "
-                         "kernels, direct = one per run straight from the storage (the reference's zero-copy form)")
+                         "kernels, direct = one per run straight from the storage (the reference's zero-copy form), shift = "
+                         "three-stage shift exchange, <= 2 messages per stage (MultiStageExchangeView)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = REHEARSAL of the multi-rank control flow with several "
                          "ranks sharing one GPU, ghost bytes staged through host memory (numbers are not a measurement)")
@@ -204,7 +205,12 @@ def run_weak(args, bl, dev, rank, world):
     stA, stB = info.allocate(512, dev), info.allocate(512, dev)
     stA.dat.uniform_(0.0, 1.0)
     A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
-    ex = Exchanger(d, stA, rank, mode=args.exchange, staged=args.backend == "gloo")
+    if args.exchange == "shift":
+        from bricklib_amd.decomp import ShiftExchanger
+        assert args.backend == "nccl" or world == 1, "the shift exchange has no host-staged rehearsal transport"
+        ex = ShiftExchanger(d, stA, rank)
+    else:
+        ex = Exchanger(d, stA, rank, mode=args.exchange, staged=args.backend == "gloo")
     if args.emulate_exchange_ms > 0:
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # calibrate torch.cuda._sleep
         torch.cuda._sleep(1000000)

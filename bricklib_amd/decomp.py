@@ -263,3 +263,117 @@ class Exchanger:
         self.exchange_begin(stream)
         self.exchange_transport(stream)
         self.exchange_end(stream)
+
+
+def _pair_runs(src_ids, dst_ids):
+    """(src start, dst start, length) runs of two equally long brick id sequences that are contiguous on both sides"""
+    src_ids, dst_ids = np.asarray(src_ids, dtype=np.int64), np.asarray(dst_ids, dtype=np.int64)
+    if src_ids.size == 0:
+        return []
+    brk = np.flatnonzero((np.diff(src_ids) != 1) | (np.diff(dst_ids) != 1)) + 1
+    starts = np.concatenate([[0], brk])
+    ends = np.concatenate([brk, [src_ids.size]])
+    return [(int(src_ids[a]), int(dst_ids[a]), int(b - a)) for a, b in zip(starts, ends)]
+
+
+class ShiftExchanger:
+    """Three-stage shift exchange (MultiStageExchangeView of include/brick-mpi.h:587-681): one stage per axis; in stage a
+    every rank trades its two boundary layers along axis a with its -a / +a neighbours, and the layers span the ghosts
+    already received along the earlier axes, so edge and corner ghosts arrive in two / three hops.  At most 2 messages
+    per stage (6 per exchange, against 26 neighbours / 42 runs), at the price of three dependent stages -- the schedule
+    for links where message count matters more than hop count (across nodes); on one xGMI node the packed all-neighbour
+    Exchanger uses all 7 links at once.  Layers are boxes of the logical grid, packed / unpacked / linked by brk_link_copy.
+    Results are identical to Exchanger's."""
+
+    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False):
+        self.d, self.st, self.rank, self.group = bDecomp, storage, rank, group
+        self.cpu = storage.dat.device.type == "cpu"
+        if self.cpu and not allow_cpu_plumbing:
+            raise RuntimeError("ShiftExchanger on CPU tensors is test plumbing only (gloo); pass allow_cpu_plumbing=True")
+        g = np.asarray(bDecomp.grid).astype(np.int64)              # [k][j][i] -> brick id
+        T = [g.shape[2], g.shape[1], g.shape[0]]
+        gb = bDecomp.depth // 8
+        step, dat = storage.step, storage.dat
+        esz = dat.element_size()
+
+        def box_ids(a, lo_a, hi_a):
+            lo, hi = [0] * 3, list(T)
+            for b in range(3):
+                if b > a:                                           # not exchanged yet: the domain only
+                    lo[b], hi[b] = gb, T[b] - gb
+            lo[a], hi[a] = lo_a, hi_a
+            return np.ascontiguousarray(g[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]).reshape(-1)
+
+        self.stages = []
+        for a in range(3):
+            minus, plus = bDecomp.rank_map[1 << (32 + a)], bDecomp.rank_map[1 << (a + 1)]
+            send = [(box_ids(a, gb, 2 * gb), minus), (box_ids(a, T[a] - 2 * gb, T[a] - gb), plus)]     # low layer, high layer
+            recv = [(box_ids(a, T[a] - gb, T[a]), plus), (box_ids(a, 0, gb), minus)]                   # high ghost, low ghost
+            links, pack, unpack, sbuf, rbuf = [], [], [], {}, {}
+            for (sids, dst), (rids, src) in zip(send, recv):
+                # my low layer is what my -a neighbour receives as its high ghost: when that neighbour is me, link directly
+                if dst == rank:
+                    links += _pair_runs(sids, rids)
+            peers_s = sorted({p for _, p in send if p != rank})
+            peers_r = sorted({p for _, p in recv if p != rank})
+            for p in peers_s:
+                n = sum(ids.size for ids, q in send if q == p) * step
+                sbuf[p] = torch.empty(n, dtype=dat.dtype, device=dat.device)
+            for p in peers_r:
+                n = sum(ids.size for ids, q in recv if q == p) * step
+                rbuf[p] = torch.empty(n, dtype=dat.dtype, device=dat.device)
+            off = {p: 0 for p in peers_s}
+            for ids, p in send:
+                if p == rank:
+                    continue
+                for s0, _, ln in _pair_runs(ids, np.arange(ids.size)):
+                    pack.append((dat, s0 * step, sbuf[p], off[p], ln * step))
+                    off[p] += ln * step
+            off = {p: 0 for p in peers_r}
+            for ids, p in recv:
+                if p == rank:
+                    continue
+                for d0, _, ln in _pair_runs(ids, np.arange(ids.size)):
+                    unpack.append((rbuf[p], off[p], dat, d0 * step, ln * step))
+                    off[p] += ln * step
+            st = {"links": [(s * step, t * step, ln * step) for s, t, ln in links], "pack": pack, "unpack": unpack,
+                  "sbuf": sbuf, "rbuf": rbuf}
+            if not self.cpu:
+                ptr = lambda t, o: t.data_ptr() + o * esz
+                st["begin"] = LinkTable([(ptr(dat, s), ptr(dat, t), ln * esz) for s, t, ln in st["links"]] +
+                                        [(ptr(x, xo), ptr(y, yo), n * esz) for x, xo, y, yo, n in pack], dat.device)
+                st["end"] = LinkTable([(ptr(x, xo), ptr(y, yo), n * esz) for x, xo, y, yo, n in unpack], dat.device)
+            self.stages.append(st)
+        self.messages = sum(len(s["sbuf"]) for s in self.stages)
+        self.bytes_remote = sum(b.numel() for s in self.stages for b in s["sbuf"].values()) * esz
+
+    def exchange(self, stream=None):
+        import torch.distributed as dist
+        dat = self.st.dat
+        for st in self.stages:
+            if self.cpu:
+                for s, t, n in st["links"]:
+                    dat[t:t + n] = dat[s:s + n].clone()
+                for a, ao, b, bo, n in st["pack"]:
+                    b[bo:bo + n] = a[ao:ao + n]
+            else:
+                st["begin"].run(stream)
+            ops = []
+            for p in sorted(set(st["rbuf"]) | set(st["sbuf"])):
+                if p in st["rbuf"]:
+                    ops.append(dist.P2POp(dist.irecv, st["rbuf"][p], p, self.group))
+                if p in st["sbuf"]:
+                    ops.append(dist.P2POp(dist.isend, st["sbuf"][p], p, self.group))
+            if ops:
+                if self.cpu or stream is None:
+                    for r in dist.batch_isend_irecv(ops):
+                        r.wait()
+                else:
+                    with torch.cuda.stream(stream):
+                        for r in dist.batch_isend_irecv(ops):
+                            r.wait()
+            if self.cpu:
+                for a, ao, b, bo, n in st["unpack"]:
+                    b[bo:bo + n] = a[ao:ao + n]
+            elif st["end"].n:
+                st["end"].run(stream)

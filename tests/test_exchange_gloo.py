@@ -27,6 +27,14 @@ def _worker(rank, world, port, dom, q, mode):
         # every element encodes (rank, brick, element) so a misrouted run is caught exactly
         v = torch.arange(d.nbricks * 512, dtype=torch.float64) + rank * 1e9
         st.dat.copy_(v)
+        if mode == "shift":
+            from bricklib_amd.decomp import ShiftExchanger
+            ex = ShiftExchanger(d, st, rank, allow_cpu_plumbing=True)
+            ex.exchange()
+            dist.barrier()
+            assert ex.messages <= 6
+            q.put((rank, st.dat.numpy().copy(), ex.messages))
+            return
         ex = Exchanger(d, st, rank, allow_cpu_plumbing=True, mode=mode)
         ex.exchange()
         dist.barrier()
@@ -35,10 +43,11 @@ def _worker(rank, world, port, dom, q, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "direct"), (4, "direct"), (2, "packed"), (4, "packed"), (8, "packed"), (8, "direct")])
+@pytest.mark.parametrize("world,mode", [(2, "direct"), (4, "direct"), (2, "packed"), (4, "packed"), (8, "packed"), (8, "direct"), (2, "shift"),
+                                        (4, "shift"), (8, "shift"), (3, "shift")])
 def test_exchange_two_ranks_gloo(oracle, world, mode):
     dom = (32, 16, 24)
-    port = 29500 + (os.getpid() % 2000) + world + (10 if mode == "packed" else 0)
+    port = 29500 + (os.getpid() % 2000) + world + {"direct": 0, "packed": 10, "shift": 20}[mode]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, dom, q, mode)) for r in range(world)]

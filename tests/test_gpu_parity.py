@@ -670,3 +670,23 @@ def test_box_list_cache_replacement(oracle, dev):
             want = np.zeros_like(hin)
             oracle.brick_stencil(NAMES["mpi13pt"], info.adj_host, hin, want, 512, ids=ids)
             assert np.abs(so.dat.cpu().numpy() - want).max() <= TOL, (rnd, lo, cnt)
+
+
+def test_shift_exchange_single_rank_equals_direct(oracle, dev):
+    """ShiftExchanger on the GPU (one periodic rank: every stage is device links) fills the ghosts exactly like the
+    run-by-run exchange; multi-rank routing is covered on CPU tensors in tests/test_exchange_gloo.py."""
+    from bricklib_amd.decomp import Exchanger, ShiftExchanger
+    d = bl.BrickDecomp((40, 24, 32))
+    bl.populate(d, [1, 1, 1], [0, 0, 0])
+    base = torch.arange(d.nbricks * 512, dtype=torch.float64)
+    res = []
+    for cls in (Exchanger, ShiftExchanger):
+        st = bl.BrickStorage(base.clone().to(dev), d.nbricks, 512)
+        cls(d, st, 0).exchange()
+        torch.cuda.synchronize()
+        res.append(st.dat.cpu())
+    assert torch.equal(res[0], res[1])
+    od = oracle.decomp((40, 24, 32))
+    want = [base.numpy().copy()]
+    oracle.exchange(od, want, [oracle.populate_rank_map([1, 1, 1], [0, 0, 0])], 512)
+    assert (res[1].numpy() == want[0]).all()
