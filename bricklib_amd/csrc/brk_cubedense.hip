@@ -48,43 +48,73 @@ extern "C" int brk_debug_stamps(unsigned long long out[8], int reset) {
 #endif
 namespace {
 
-template <int R>
+template <int KIND>
 struct DenseTile {
+  static constexpr int R = CubeTraits<KIND>::R;
   static constexpr int T = 8 + 2 * R;
-  static constexpr int ELEMS = T * T * 8;
+  // planes of the halo'd brick kept in LDS: all T of them, except for the diamond, whose outermost levels stay in registers
+  static constexpr int KK0 = KIND == kDiamond25 ? 1 : 0, NPL = KIND == kDiamond25 ? T - 2 : T;
+  static constexpr int ELEMS = NPL * T * 8;
   static_assert(ELEMS % 32 == 0, "sibling tiles must keep the bank pattern");
-  __host__ __device__ static constexpr int at(int kk, int jj, int c) { return (kk * T + jj) * 8 + c; }
-  // edge/corner cells of the halo, grouped by the side they are staged on (each group padded to whole 64-lane gathers)
-  static constexpr int N0 = 4 * R * R * 8;              // di = 0: the four k-j edges
-  static constexpr int NS = (T * T - 64) * R;           // di = -1 (or +1): every (k,j) row outside the i-face itself
-  static constexpr int IT0 = (N0 + 63) / 64, ITS = (NS + 63) / 64;
-  static constexpr int EXTRA_ITERS = IT0 + 2 * ITS;
+  __host__ __device__ static constexpr int at(int kk, int jj, int c) { return ((kk - KK0) * T + jj) * 8 + c; }
+  __host__ __device__ static constexpr bool has_plane(int kk) { return kk >= KK0 && kk < KK0 + NPL; }
 };
 
 // One descriptor per cell:
 //   offset inside the destination slot | adjacency slot << 16 | element offset inside the source brick << 21
 // Group 0 (di = 0) goes into the wave's own tile, group 1 (di = -1) into columns 8-R..7 of the slot on the left, group 2
 // (di = +1) into columns 0..R-1 of the slot on the right; a wave whose i-neighbour is a sibling skips that group entirely.
-template <int R>
-struct DenseExtra {
-  uint32_t e[DenseTile<R>::EXTRA_ITERS * 64];
+// The full cubes need every edge/corner cell of the halo; the 25-point diamond (two fused 7-point sweeps) only the twelve
+// one-cell-wide edge lines next to the brick.
+template <int KIND>
+struct DX {
+  static constexpr int R = CubeTraits<KIND>::R;
+  static constexpr int T = 8 + 2 * R;
+  __host__ __device__ static constexpr bool wanted(int kk, int jj, int ii) {
+    const int dk = kk < R ? -1 : (kk >= R + 8 ? 1 : 0), dj = jj < R ? -1 : (jj >= R + 8 ? 1 : 0);
+    const int di = ii < R ? -1 : (ii >= R + 8 ? 1 : 0);
+    if ((dk != 0) + (dj != 0) + (di != 0) < 2) return false; // own brick and faces are staged by structured loads
+    if (KIND != kDiamond25) return true;
+    // distance of the cell from the brick along each axis (0 inside): the diamond reaches L1 distance 2
+    const int ek = kk < R ? R - kk : (kk >= R + 8 ? kk - R - 7 : 0), ej = jj < R ? R - jj : (jj >= R + 8 ? jj - R - 7 : 0);
+    const int ei = ii < R ? R - ii : (ii >= R + 8 ? ii - R - 7 : 0);
+    return ek + ej + ei <= 2;
+  }
+  static constexpr int count(int side) {
+    int n = 0;
+    for (int kk = 0; kk < T; ++kk)
+      for (int jj = 0; jj < T; ++jj)
+        for (int ii = 0; ii < T; ++ii) {
+          const int di = ii < R ? -1 : (ii >= R + 8 ? 1 : 0);
+          if (wanted(kk, jj, ii) && (di < 0 ? 1 : (di > 0 ? 2 : 0)) == side) ++n;
+        }
+    return n;
+  }
+  static constexpr int IT0 = (count(0) + 63) / 64, ITS = (count(1) + 63) / 64;
+  static constexpr int EXTRA_ITERS = IT0 + 2 * ITS;
 };
 
-template <int R>
-constexpr DenseExtra<R> make_dense_extra() {
-  DenseExtra<R> t{};
-  using TL = DenseTile<R>;
-  constexpr int T = 8 + 2 * R;
-  for (int q = 0; q < TL::EXTRA_ITERS * 64; ++q) t.e[q] = 0xFFFFFFFFu;
+template <int KIND>
+struct DenseExtra {
+  uint32_t e[DX<KIND>::EXTRA_ITERS * 64];
+};
+
+template <int KIND>
+constexpr DenseExtra<KIND> make_dense_extra() {
+  DenseExtra<KIND> t{};
+  using X = DX<KIND>;
+  constexpr int R = X::R, T = X::T;
+  using TL = DenseTile<KIND>;
+  for (int q = 0; q < X::EXTRA_ITERS * 64; ++q) t.e[q] = 0xFFFFFFFFu;
   for (int side = 0; side < 3; ++side) {
-    int n = (side == 0 ? 0 : (side == 1 ? TL::IT0 : TL::IT0 + TL::ITS)) * 64;
+    int n = (side == 0 ? 0 : (side == 1 ? X::IT0 : X::IT0 + X::ITS)) * 64;
     for (int kk = 0; kk < T; ++kk)
       for (int jj = 0; jj < T; ++jj)
         for (int ii = 0; ii < T; ++ii) {
           const int dk = kk < R ? -1 : (kk >= R + 8 ? 1 : 0);
           const int dj = jj < R ? -1 : (jj >= R + 8 ? 1 : 0);
           const int di = ii < R ? -1 : (ii >= R + 8 ? 1 : 0);
-          if ((dk != 0) + (dj != 0) + (di != 0) < 2) continue;
+          if (!X::wanted(kk, jj, ii)) continue;
           if ((di < 0 ? 1 : (di > 0 ? 2 : 0)) != side) continue;
           const int sk = (kk - R + 8) % 8, sj = (jj - R + 8) % 8, si = (ii - R + 8) % 8;
           const int col = di < 0 ? 8 - R + ii : (di > 0 ? ii - R - 8 : ii - R);
@@ -95,12 +125,14 @@ constexpr DenseExtra<R> make_dense_extra() {
   return t;
 }
 
-__device__ const DenseExtra<1> g_dense1 = make_dense_extra<1>();
-__device__ const DenseExtra<2> g_dense2 = make_dense_extra<2>();
-template <int R>
+__device__ const DenseExtra<kCube27> g_dense27 = make_dense_extra<kCube27>();
+__device__ const DenseExtra<kCube125> g_dense125 = make_dense_extra<kCube125>();
+__device__ const DenseExtra<kDiamond25> g_dense_d25 = make_dense_extra<kDiamond25>();
+template <int KIND>
 __device__ __forceinline__ const uint32_t *dense_table() {
-  if (R == 1) return g_dense1.e;
-  return g_dense2.e;
+  if (KIND == kCube27) return g_dense27.e;
+  if (KIND == kCube125) return g_dense125.e;
+  return g_dense_d25.e;
 }
 
 // Do bricks `left` and `right` (adjacency rows in lanes 0..26 of rl / rr) see the same world across their common i-face?
@@ -118,7 +150,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
     const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
   constexpr int R = CubeTraits<KIND>::R;
-  using TL = DenseTile<R>;
+  using TL = DenseTile<KIND>;
+  using X = DX<KIND>;
   constexpr int E = TL::ELEMS;
   __shared__ double lds[(NW + 1) * E];
   __shared__ uint32_t breaks[NW];
@@ -137,18 +170,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   // The descriptors of the edge/corner gathers depend on the lane only.  They are requested before anything else: a load
   // issued after the brick's own loads returns after them (vector loads complete in order), and the gathers, which need
   // the descriptors for their addresses, would wait for a full round trip of the brick before they could even be issued.
-  uint32_t xd[TL::EXTRA_ITERS];
+  uint32_t xd[X::EXTRA_ITERS];
   {
-    const uint32_t *xt = dense_table<R>();
+    const uint32_t *xt = dense_table<KIND>();
 #pragma unroll
-    for (int t = 0; t < TL::EXTRA_ITERS; ++t) xd[t] = xt[t * 64 + lane];
+    for (int t = 0; t < X::EXTRA_ITERS; ++t) xd[t] = xt[t * 64 + lane];
   }
   STAMP(t0);
   const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;
   const bool active = b != BRK_LIST_SKIP;
   bool link_l = false, link_r = false, brk_l = false;
   double own[8], fkm[R], fkp[R], fjm[R], fjp[R], fim[R], fip[R];
-  double xv[TL::EXTRA_ITERS];
+  double xv[X::EXTRA_ITERS];
   if (active) {
     const uint32_t b_prev = w > 0 ? __builtin_amdgcn_readfirstlane(id_of(slot - 1)) : BRK_LIST_SKIP;
     const uint32_t b_next = (w + 1 < NW && slot + 1 < n) ? __builtin_amdgcn_readfirstlane(id_of(slot + 1)) : BRK_LIST_SKIP;
@@ -207,14 +240,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
       xv[t] = xd[t] != 0xFFFFFFFFu ? in[(size_t)nb * step + ((xd[t] >> 21) & 511u)] : 0.0;
     };
 #pragma unroll
-    for (int t = 0; t < TL::IT0; ++t) gather(t);
+    for (int t = 0; t < X::IT0; ++t) gather(t);
     if (!link_l) {
 #pragma unroll
-      for (int t = TL::IT0; t < TL::IT0 + TL::ITS; ++t) gather(t);
+      for (int t = X::IT0; t < X::IT0 + X::ITS; ++t) gather(t);
     }
     if (!link_r) {
 #pragma unroll
-      for (int t = TL::IT0 + TL::ITS; t < TL::EXTRA_ITERS; ++t) gather(t);
+      for (int t = X::IT0 + X::ITS; t < X::EXTRA_ITERS; ++t) gather(t);
     }
   }
   STAMP(t1); // everything is requested
@@ -239,8 +272,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
       for (int k = 0; k < 8; ++k) tile[TL::at(k + R, hi + R, lo)] = own[k];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        tile[TL::at(r, hi + R, lo)] = fkm[r];
-        tile[TL::at(R + 8 + r, hi + R, lo)] = fkp[r];
+        if (TL::has_plane(r)) tile[TL::at(r, hi + R, lo)] = fkm[r];
+        if (TL::has_plane(R + 8 + r)) tile[TL::at(R + 8 + r, hi + R, lo)] = fkp[r];
         tile[TL::at(hi + R, r, lo)] = fjm[r];
         tile[TL::at(hi + R, R + 8 + r, lo)] = fjp[r];
       }
@@ -253,16 +286,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
         for (int r = 0; r < R; ++r) right[TL::at(hi + R, lo + R, r)] = fip[r];
       }
 #pragma unroll
-      for (int t = 0; t < TL::IT0; ++t)
+      for (int t = 0; t < X::IT0; ++t)
         if (xd[t] != 0xFFFFFFFFu) tile[xd[t] & 0xFFFFu] = xv[t];
       if (!link_l) {
 #pragma unroll
-        for (int t = TL::IT0; t < TL::IT0 + TL::ITS; ++t)
+        for (int t = X::IT0; t < X::IT0 + X::ITS; ++t)
           if (xd[t] != 0xFFFFFFFFu) left[xd[t] & 0xFFFFu] = xv[t];
       }
       if (!link_r) {
 #pragma unroll
-        for (int t = TL::IT0 + TL::ITS; t < TL::EXTRA_ITERS; ++t)
+        for (int t = X::IT0 + X::ITS; t < X::EXTRA_ITERS; ++t)
           if (xd[t] != 0xFFFFFFFFu) right[xd[t] & 0xFFFFu] = xv[t];
       }
     }
@@ -284,7 +317,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
         const int c = lo + di;
         col[di + R] = c < 0 ? -E + c + 8 : (c > 7 ? roff + c - 8 : c);
       }
-      if (KIND == kCube125) {
+      if (KIND == kDiamond25) {
+        const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
+        diamond25_accumulate<TL::T * 8, 8>(tile + TL::at(0, hi + R, 0), co, cf, dst, lane, fkm[0], fkp[R - 1]);
+      } else if (KIND == kCube125) {
         const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
         if (PIPE == 1) cube125_accumulate<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
         else if (PIPE == 2) cube125_accumulate_static<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
@@ -328,7 +364,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8, wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
-  if (stencil_id == BRK_27PT_COEFF) {
+  if (stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2) {
+    hipLaunchKernelGGL((k_cube_dense<kDiamond25, 4, 4>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (stencil_id == BRK_27PT_COEFF) {
     if (variant == 5)
       hipLaunchKernelGGL((k_cube_dense<kCube27, 8, 4>), dim3(wgs8), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
     else

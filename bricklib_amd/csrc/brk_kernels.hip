@@ -152,21 +152,44 @@ __global__ __launch_bounds__(kWG) void k_iter(IterGeom g, double *__restrict__ a
   }
 }
 
-int g_variant[BRK_NSTENCIL] = {0, 0, 0, 0, 0, 0, 0};
+int g_variant[BRK_NSTENCIL] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 constexpr int kDefaultStar7Variant = 5; // 8-wave workgroups sharing i-faces through LDS (brk_star7.hip)
 
 // defaults: stencils/fake.h:11-33
 const double kDefault[BRK_NSTENCIL][10] = {{0}, {0}, {0.4, 0.1}, {0.4, 0.07, 0.03}, {0.1, 0.06, 0.045, 0.03, 0.015},
-                                           {0.1, 0.04, 0.03, 0.01, 0.006, 0.004, 0.005, 0.002, 0.003, 0.001}, {0}};
+                                           {0.1, 0.04, 0.03, 0.01, 0.006, 0.004, 0.005, 0.002, 0.003, 0.001}, {0}, {0}, {0}};
 
 int make_coeffs(int id, const double *host, Coeffs &cf) {
   std::memset(&cf, 0, sizeof cf);
   const int nc = brk_stencil_ncoeff(id);
   if (nc < 0) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
   if (!host) {
-    if (id == BRK_7PT_COEFF || id == BRK_27PT_COEFF || id == BRK_COND7)
+    if (id == BRK_7PT_COEFF || id == BRK_27PT_COEFF || id == BRK_COND7 || id == BRK_7PT_X2)
       return brk_fail(BRK_EINVAL, "stencil %d needs a coefficient vector", id);
-    host = kDefault[id];
+    host = kDefault[id == BRK_MPI7_X2 ? BRK_MPI7 : id];
+  }
+  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) {
+    // weights of S*S: w[dk+1][dj+1][di+1] of one sweep (7pt.py order: centre, i+1, i-1, j+1, j-1, k+1, k-1), convolved with itself
+    double w[3][3][3] = {};
+    if (id == BRK_MPI7_X2) {
+      w[1][1][1] = host[0];
+      w[1][1][2] = w[1][1][0] = w[1][2][1] = w[1][0][1] = w[2][1][1] = w[0][1][1] = host[1];
+    } else {
+      w[1][1][1] = host[0], w[1][1][2] = host[1], w[1][1][0] = host[2], w[1][2][1] = host[3], w[1][0][1] = host[4];
+      w[2][1][1] = host[5], w[0][1][1] = host[6];
+    }
+    for (int t = 0; t < 25; ++t) {
+      double c = 0.0;
+      for (int uk = -1; uk <= 1; ++uk)
+        for (int uj = -1; uj <= 1; ++uj)
+          for (int ui = -1; ui <= 1; ++ui) {
+            const int vk = kDiamondTaps[t].dk - uk, vj = kDiamondTaps[t].dj - uj, vi = kDiamondTaps[t].di - ui;
+            if (vk < -1 || vk > 1 || vj < -1 || vj > 1 || vi < -1 || vi > 1) continue;
+            c += w[uk + 1][uj + 1][ui + 1] * w[vk + 1][vj + 1][vi + 1];
+          }
+      cf.c[t] = c;
+    }
+    return BRK_OK;
   }
   if (id == BRK_27PT_COEFF) {
     // weights per offset slot; the reference applies coeff[16] to (k+1,j+1,i) instead of (k,j+1,i)
@@ -200,6 +223,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   // one-wave kernel, 27-pt variant 2 and 125-pt variants 2/4/8 = padded tiles with shared i-halos (brk_cubewg.hip),
   // 125-pt variant 3 = generic kernel with 4 waves per workgroup.  Measured at 512^3 (profiles/): 27-pt 0.555 (padded,
   // 8 waves) -> 0.43 ms; 125-pt 1.06 (generic) -> 0.70 ms.
+  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, 0, adj, in, out, step, ids, first, n, cf, st);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = g_variant[id];
     if (v == 0 || (v >= 5 && v <= 9)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st);

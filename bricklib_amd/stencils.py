@@ -8,7 +8,9 @@ from .brick import _ptr, _stream
 
 # name -> id; names follow the reference's stencil scripts (stencils/*.py) and drivers
 STENCILS = {"7pt": BRK_7PT_COEFF, "27pt": BRK_27PT_COEFF, "mpi7pt": BRK_MPI7, "mpi13pt": BRK_MPI13,
-            "mpi25pt": BRK_MPI25, "mpi125pt": BRK_MPI125, "cond": 6}
+            "mpi25pt": BRK_MPI25, "mpi125pt": BRK_MPI125, "cond": 6,
+            # two consecutive 7-point sweeps in one pass (not in the reference; see include/brk.h)
+            "mpi7pt_x2": 7, "7pt_x2": 8}
 
 
 def _sid(stencil):

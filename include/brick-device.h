@@ -218,10 +218,52 @@ __device__ __forceinline__ const uint32_t *extra_table() {
   return g_extra2.e;
 }
 
-enum CubeKind { kCube27, kCube125 };
+enum CubeKind { kCube27, kCube125, kDiamond25 };
 template <int KIND> struct CubeTraits;
 template <> struct CubeTraits<kCube27> { static constexpr int R = 1; };
 template <> struct CubeTraits<kCube125> { static constexpr int R = 2; };
+template <> struct CubeTraits<kDiamond25> { static constexpr int R = 2; };
+
+// Two sweeps of a 7-point star in one pass: S*S has 25 taps, the points within L1 distance 2.  Tap t of the table below has
+// weight Coeffs::c[t]; the launcher fills c[t] = sum over pairs (u, v) of star offsets (incl. 0) with u + v = tap of w(u) w(v).
+struct Tap3 {
+  int dk, dj, di;
+};
+constexpr Tap3 kDiamondTaps[25] = {
+    {0, 0, 0},  {0, 0, 1},  {0, 0, -1}, {0, 1, 0},  {0, -1, 0}, {0, 0, 2},  {0, 0, -2},  {0, 2, 0},  {0, -2, 0},
+    {0, 1, 1},  {0, 1, -1}, {0, -1, 1}, {0, -1, -1},                                                     // dk = 0: 13
+    {1, 0, 0},  {1, 0, 1},  {1, 0, -1}, {1, 1, 0},  {1, -1, 0},                                           // dk = +1: 5
+    {-1, 0, 0}, {-1, 0, 1}, {-1, 0, -1}, {-1, 1, 0}, {-1, -1, 0},                                         // dk = -1: 5
+    {2, 0, 0},  {-2, 0, 0}};
+
+// Scatter form over the planes of an R = 2 tile, fully unrolled with one fence per plane (see cube125_accumulate_static):
+// plane kk holds input level k_in = kk - 2 and feeds the outputs k = k_in - dk.  Reads per plane: 13 (a level that feeds an
+// output of its own k) or 5 (only |dk| = 1 outputs): 114 per lane instead of 300 for the full cube.  The two outermost
+// levels (k_in = -2 and 9) only ever meet the centre tap of |dk| = 2, i.e. the lane's own column: they stay in registers
+// (below, above) and the tile holds the 10 planes kk = 1..10 (rowp points at the virtual plane 0).
+template <int PS, int RS, class DST>
+__device__ __forceinline__ void diamond25_accumulate(const double *rowp, const int (&co)[5], const Coeffs &cf, DST dst, int lane,
+                                                     double below, double above) {
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+  acc[0] = cf.c[24] * below; // tap (-2,0,0): out[0] reads level -2
+  const double *colp[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) colp[d] = rowp + co[d];
+#pragma unroll
+  for (int kk = 1; kk < 11; ++kk) {
+    const int kin = kk - 2;
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+      const int k = kin - kDiamondTaps[t].dk; // output this tap of this plane feeds
+      if (k >= 0 && k < 8) acc[k] += cf.c[t] * colp[kDiamondTaps[t].di + 2][kk * PS + kDiamondTaps[t].dj * RS];
+    }
+    if (kk >= 4) store_result(&dst[(kk - 4) * 64 + lane], acc[kk - 4]); // output kk-4 has received its last plane
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  store_result(&dst[7 * 64 + lane], acc[7] + cf.c[23] * above); // tap (+2,0,0): out[7] reads level 9
+}
 
 // coefficient class of a 125-pt offset: sorted(|di|,|dj|,|dk|) -> 0..9 (stencils/mpi125pt.py:12-33)
 __host__ __device__ constexpr int cls125(int a, int b, int c) {

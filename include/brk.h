@@ -48,8 +48,14 @@ enum {
  *  BRK_MPI13  {B0,B1,B2}        stencils/mpi13pt.py, fake.h:20-22,71-84             (NULL -> defaults)
  *  BRK_MPI25  {A0..A4}          stencils/mpi25pt.py, fake.h:14-18,41-70             (NULL -> defaults)
  *  BRK_MPI125 {C0..C9}          stencils/mpi125pt.py, fake.h:24-33,90-343           (NULL -> defaults)
- *  BRK_COND7  coeff[0..6]       stencils/cond.py, stencils/3axis.cpp:94-163 (d3cond): |sum c_t * max(in_t, 0)| */
-enum { BRK_7PT_COEFF = 0, BRK_27PT_COEFF = 1, BRK_MPI7 = 2, BRK_MPI13 = 3, BRK_MPI25 = 4, BRK_MPI125 = 5, BRK_COND7 = 6, BRK_NSTENCIL = 7 };
+ *  BRK_COND7  coeff[0..6]       stencils/cond.py, stencils/3axis.cpp:94-163 (d3cond): |sum c_t * max(in_t, 0)|
+ *  BRK_MPI7_X2, BRK_7PT_X2     TWO consecutive sweeps of BRK_MPI7 / BRK_7PT_COEFF in one pass over memory (same coefficient
+ *                               vectors): out = S(S(in)), evaluated as the 25-point radius-2 stencil S*S whose weights are
+ *                               the products of the 7-point weights.  Not in the reference; used by the weak / strong
+ *                               drivers to halve the HBM traffic of a communication-avoiding cycle (ST_ITER sweeps between
+ *                               exchanges, weak/main.cpp:186-207).  Agrees with two separate sweeps to rounding (~1e-16). */
+enum { BRK_7PT_COEFF = 0, BRK_27PT_COEFF = 1, BRK_MPI7 = 2, BRK_MPI13 = 3, BRK_MPI25 = 4, BRK_MPI125 = 5, BRK_COND7 = 6,
+       BRK_MPI7_X2 = 7, BRK_7PT_X2 = 8, BRK_NSTENCIL = 9 };
 
 const char *brk_last_error(void);
 /* 7*1000+... style version of this ABI */

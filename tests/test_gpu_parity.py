@@ -690,3 +690,47 @@ def test_shift_exchange_single_rank_equals_direct(oracle, dev):
     want = [base.numpy().copy()]
     oracle.exchange(od, want, [oracle.populate_rank_map([1, 1, 1], [0, 0, 0])], 512)
     assert (res[1].numpy() == want[0]).all()
+
+
+@pytest.mark.parametrize("name", ["mpi7pt", "7pt"])
+def test_fused_double_sweep(oracle, dev, name):
+    """BRK_MPI7_X2 / BRK_7PT_X2: one pass = two 7-point sweeps.  Against two separate GPU sweeps (same bricks, the first over
+    a ring more) and against the oracle's two array sweeps; list with skipped entries and BrickDecomp range incl. ghost."""
+    from bricklib_amd.order import LIST_SKIP, tiled
+    coeff = oracle.coeffs(129, 1) if name == "7pt" else None
+    N = 40                                               # cells; array with 16 cells of padding+ghost per side as in single_setup
+    grid, grid_dev, bInfo, arr, st, bIn, ids = single_setup(oracle, dev, N, 512)
+    SB = (N + 16) // 8
+    g3 = grid.reshape(SB, SB, SB)
+    inner = tiled(g3[2:-2, 2:-2, 2:-2])                  # bricks whose 2-cell neighbourhood lies inside the filled region
+    ring = tiled(g3[1:-1, 1:-1, 1:-1])
+    mid, two, fused = (bl.BrickStorage.allocate(bInfo.nbricks, 512, dev) for _ in range(3))
+    B = lambda s: bl.Brick(bInfo, s, 0)
+    bl.apply_stencil(name, bIn, B(mid), ids=grid_to_device(ring, dev), coeff=coeff)
+    bl.apply_stencil(name, B(mid), B(two), ids=grid_to_device(inner, dev), coeff=coeff)
+    bl.apply_stencil(name + "_x2", bIn, B(fused), ids=grid_to_device(inner, dev), coeff=coeff)
+    real = torch.from_numpy(inner[inner != LIST_SKIP].astype(np.int64)).to(dev)
+    a, b = two.dat.view(-1, 512)[real], fused.dat.view(-1, 512)[real]
+    assert (a - b).abs().max().item() <= TOL
+    mask = torch.ones(bInfo.nbricks, dtype=torch.bool, device=dev)
+    mask[real] = False
+    assert (fused.dat.view(-1, 512)[mask] == 0).all()    # bricks outside the list are untouched
+    # oracle: two array sweeps
+    a1, a2 = np.zeros_like(arr), np.zeros_like(arr)
+    oracle.array_stencil(NAMES[name], arr, a1, (9,) * 3, (arr.shape[0] - 9,) * 3, coeff=coeff)
+    oracle.array_stencil(NAMES[name], a1, a2, (24,) * 3, (N + 8,) * 3, coeff=coeff)   # bricks 2..SB-3 = array cells 24..N+8
+    got = torch.zeros(arr.shape, dtype=torch.float64, device=dev)
+    bl.copyFromBrick((N + 16,) * 3, (8,) * 3, (0,) * 3, got, grid_dev, B(fused))
+    sl = (slice(24, N + 8),) * 3
+    assert np.abs(got.cpu().numpy()[sl] - a2[sl]).max() <= TOL
+    # range form over a BrickDecomp numbering incl. the ghost ring: equals two sweeps wherever two sweeps are defined
+    d = bl.BrickDecomp((32, 24, 40))
+    dinfo = d.getBrickInfo(dev)
+    A, M, T2, F = (dinfo.allocate(512, dev) for _ in range(4))
+    A.dat.uniform_(0.0, 1.0)
+    A.dat[:512] = 0
+    Bd = lambda s: bl.Brick(dinfo, s, 0)
+    bl.apply_stencil(name, Bd(A), Bd(M), brick_range=(1, d.sep_pos[2]), coeff=coeff)
+    bl.apply_stencil(name, Bd(M), Bd(T2), brick_range=(1, d.sep_pos[1]), coeff=coeff)
+    bl.apply_stencil(name + "_x2", Bd(A), Bd(F), brick_range=(1, d.sep_pos[1]), coeff=coeff)
+    assert (T2.dat[512:512 * d.sep_pos[1]] - F.dat[512:512 * d.sep_pos[1]]).abs().max().item() <= TOL
