@@ -9,8 +9,9 @@ N = 1  workload "single-7pt-512": the reference's single/hip d3pt7 `Trans` launc
        and output fields in two storages (--layout interleaved = one storage as in single/, 1.5 % slower).
 N > 1  workload "weak-mpi7pt-512": weak/main.cu shape: BrickDecomp 512^3 per rank on a periodic MPI_Dims_create(N) grid,
        one step = one brick_func = ghost exchange (per-peer pack -> RCCL send/recv -> unpack, device links for
-       self-neighbours) + ST_ITER = 8 sweeps, the exchange hidden behind the part of the sweeps that cannot depend on it
-       yet (--schedule).  GStencil/s counts useful updates only (weak/main.cpp:285-287).
+       self-neighbours) + ST_ITER = 8 sweeps -- by default as 4 passes over memory of 2 sweeps each (--fuse) -- the exchange
+       hidden behind the part of the passes that cannot depend on it yet (--schedule).  GStencil/s counts useful updates
+       only (weak/main.cpp:285-287).
 Other workloads: --workload weak at N = 1, --workload strong (global 1024^3 in 128^3 subdomains, 13-point).
 Prints ONE JSON line on rank 0.  Inputs are synthetic U[0,1) already resident in HBM when timing starts.
 """
@@ -68,6 +69,9 @@ def parse():
                          "reference's weak/strong drivers); interleaved = both fields in one storage (step 1024, the layout of "
                          "single/: 3axis.cpp:25-28).  Same kernels; interleaving reads and writes in the same DRAM pages costs "
                          "1.5 % (7-pt) to 10 % (27-pt) on MI355X (profiles/r01_h_layouts.json)")
+    ap.add_argument("--fuse", type=int, default=2, choices=(1, 2),
+                    help="weak workload with the 7-point stencil: 2 = every pass over memory performs two of the ST_ITER = 8 sweeps "
+                         "between exchanges (BRK_MPI7_X2, the 25-point S*S stencil; results equal to rounding), 1 = one sweep per pass")
     ap.add_argument("--deep-depth", type=int, default=0,
                     help="--schedule deep: split only the first K sweeps into early/late passes (0 = all ST_ITER sweeps)")
     ap.add_argument("--emulate-exchange-ms", type=float, default=0.0,
@@ -194,7 +198,7 @@ def run_weak(args, bl, dev, rank, world):
     from bricklib_amd.drivers import weak_cycle
     from bricklib_amd.stencils import STENCILS
     N = args.n
-    name = args.stencil or "mpi7pt"
+    name = args.stencil or ("mpi7pt_x2" if args.fuse == 2 else "mpi7pt")
     sid = STENCILS[name]
     K = args.steps if args.steps is not None else 25
     W = args.warmup if args.warmup is not None else 3
@@ -281,8 +285,8 @@ def run_weak(args, bl, dev, rank, world):
         # while it overlaps with sweeps the exchange is taken to progress 1.2x slower (shared HBM): a window of h ms of
         # independent compute retires h / 1.2 ms of exchange
         cost = {("plain", 0): T + probe_ms, ("surface", 0): 1.03 * T + max(0.0, probe_ms - 0.2 * T / 1.2)}
-        for k in range(2, S + 1):                               # deep with k split sweeps: +0.8 % per level, measured at k = 8
-            cost[("deep", k)] = (1.0 + 0.008 * k) * T + max(0.0, probe_ms - sum(share[:k]) * sweep_ms / 1.2)
+        for k in range(2, S + 1):                               # deep with k split passes: +6 % at full depth (measured)
+            cost[("deep", k)] = (1.0 + 0.06 * k / S) * T + max(0.0, probe_ms - sum(share[:k]) * sweep_ms / 1.2)
         schedule, deep_depth = min(cost, key=cost.get)
     overlap = schedule != "plain"
     state = {}
@@ -332,11 +336,12 @@ def run_weak(args, bl, dev, rank, world):
     exchange_ms = xs.elapsed_time(x1) / 5
     sum1 = global_sum()
     # weights of the MPI_* stencils add up to 1 (fake.h:11-33): 0.4+6(.1); .4+6(.07+.03); .1+6(.06+.045+.03+.015); C0..C9 x multiplicities
-    drift = abs(sum1 - sum0) / abs(sum0) if name in ("mpi7pt", "mpi13pt", "mpi25pt", "mpi125pt") else None
-    cells = float(N) ** 3 * S * world
-    res = {"workload": f"weak-{name}-{N}", "conservation_rel_drift": drift, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
-           "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,
-           "kernel": "%s sweeps over brick lists of BrickDecomp(%d^3): %d sweeps + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S),
+    drift = abs(sum1 - sum0) / abs(sum0) if name in ("mpi7pt", "mpi13pt", "mpi25pt", "mpi125pt", "mpi7pt_x2") else None
+    upd = 2 if name.endswith("_x2") else 1                 # a fused pass updates every cell twice
+    cells = float(N) ** 3 * S * upd * world
+    res = {"workload": f"weak-{name[:-3] if upd == 2 else name}-{N}", "conservation_rel_drift": drift, "updates_per_pass": upd, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+           "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,   # per pass: one read + one write per cell
+           "kernel": "%s passes over brick lists of BrickDecomp(%d^3): %d passes (%d sweeps) + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S * upd, S),
            "cart": cart, "overlap": overlap, "exchange": args.exchange, "schedule": schedule, "deep_depth": deep_depth if schedule == "deep" else None, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
            "remote_bytes_per_rank": ex.bytes_remote}
     return res, {}
@@ -439,7 +444,7 @@ def main():
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
-                       **{k: res[k] for k in ("layout", "form", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
+                       **{k: res[k] for k in ("layout", "form", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],

@@ -161,6 +161,13 @@ def test_weak_cycle_virtual_ranks(oracle, dev, name, nranks):
     _weak_virtual(oracle, dev, name, nranks, (16, 16, 16), "lists" if nranks != 2 else "ranges")
 
 
+@pytest.mark.parametrize("schedule,nranks", [("lists", 1), ("lists", 8), ("ranges", 2), ("deep", 4)])
+def test_weak_cycle_fused_double_sweeps(oracle, dev, schedule, nranks):
+    """the weak cycle with BRK_MPI7_X2 (4 fused passes = the 8 sweeps of mpi7pt between two exchanges) against the global
+    periodic field swept 8 times per cycle on the CPU, every schedule"""
+    _weak_virtual(oracle, dev, "mpi7pt_x2", nranks, (40, 32, 48) if schedule == "deep" else (16, 16, 16), schedule)
+
+
 @pytest.mark.parametrize("name,nranks", [("mpi7pt", 2), ("mpi7pt", 8), ("mpi13pt", 4), ("mpi25pt", 1)])
 def test_weak_cycle_deep_schedule_virtual_ranks(oracle, dev, name, nranks):
     """the deep-overlap schedule (drivers.weak_cycle_deep: early shrinking-box passes of every sweep, then the shells)
@@ -206,12 +213,14 @@ def _weak_virtual(oracle, dev, name, nranks, dom, schedule):
     # oracle: global periodic field, wrap-padded by 8 cells, S sweeps per cycle
     gext = tuple(g + 16 for g in gdims)
     cur = oracle.fill_array_global(gext, (-8, -8, -8), gdims, seed)
-    R = oracle.radius(NAMES[name])
+    oname = name[:-3] if name.endswith("_x2") else name     # a fused pass = two sweeps of the base stencil
+    osweeps = S * 2 if name.endswith("_x2") else S
+    R = oracle.radius(NAMES[oname])
     for _ in range(ncycles):
-        for s in range(1, S + 1):
+        for s in range(1, osweeps + 1):
             nxt = np.zeros_like(cur)
             m = s * R
-            oracle.array_stencil(NAMES[name], cur, nxt, (m,) * 3, tuple(g - m for g in gext))
+            oracle.array_stencil(NAMES[oname], cur, nxt, (m,) * 3, tuple(g - m for g in gext))
             cur = nxt
         core = cur[8:-8, 8:-8, 8:-8].copy()
         cur = np.pad(core, 8, mode="wrap")
