@@ -319,7 +319,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
       }
       if (KIND == kDiamond25) {
         const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
-        diamond25_accumulate<TL::T * 8, 8>(tile + TL::at(0, hi + R, 0), co, cf, dst, lane, fkm[0], fkp[R - 1]);
+        diamond25_accumulate<TL::T * 8, 8, PIPE == 1>(tile + TL::at(0, hi + R, 0), co, cf, dst, lane, fkm[0], fkp[R - 1]);
       } else if (KIND == kCube125) {
         const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
         if (PIPE == 1) cube125_accumulate<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
@@ -364,7 +364,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8, wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
-  if (stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2) {
+  if ((stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2) && variant == 2) { // plane loop without read-ahead
+    hipLaunchKernelGGL((k_cube_dense<kDiamond25, 4, 4, 0>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2) {
     hipLaunchKernelGGL((k_cube_dense<kDiamond25, 4, 4>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   } else if (stencil_id == BRK_27PT_COEFF) {
     if (variant == 5)

@@ -223,7 +223,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   // one-wave kernel, 27-pt variant 2 and 125-pt variants 2/4/8 = padded tiles with shared i-halos (brk_cubewg.hip),
   // 125-pt variant 3 = generic kernel with 4 waves per workgroup.  Measured at 512^3 (profiles/): 27-pt 0.555 (padded,
   // 8 waves) -> 0.43 ms; 125-pt 1.06 (generic) -> 0.70 ms.
-  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, 0, adj, in, out, step, ids, first, n, cf, st);
+  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, g_variant[id], adj, in, out, step, ids, first, n, cf, st);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = g_variant[id];
     if (v == 0 || (v >= 5 && v <= 9)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st);

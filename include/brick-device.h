@@ -241,7 +241,15 @@ constexpr Tap3 kDiamondTaps[25] = {
 // output of its own k) or 5 (only |dk| = 1 outputs): 114 per lane instead of 300 for the full cube.  The two outermost
 // levels (k_in = -2 and 9) only ever meet the centre tap of |dk| = 2, i.e. the lane's own column: they stay in registers
 // (below, above) and the tile holds the 10 planes kk = 1..10 (rowp points at the virtual plane 0).
-template <int PS, int RS, class DST>
+// in-plane positions (dj, di) a plane can be asked for: the first 5 serve the |dk| = 1 taps, all 13 the dk = 0 taps
+struct Pos2 {
+  int dj, di;
+};
+constexpr Pos2 kDiamondPos[13] = {{0, 0}, {0, 1}, {0, -1}, {1, 0}, {-1, 0}, {0, 2}, {0, -2}, {2, 0}, {-2, 0}, {1, 1}, {1, -1}, {-1, 1}, {-1, -1}};
+constexpr int diamond_pos_of_tap(int t) { return t < 13 ? t : (t < 18 ? t - 13 : (t < 23 ? t - 18 : 0)); }
+constexpr int diamond_reads_of_plane(int kk) { return (kk >= 2 && kk <= 9) ? 13 : 5; } // levels 0..7 feed their own output
+
+template <int PS, int RS, bool PIPELINED, class DST>
 __device__ __forceinline__ void diamond25_accumulate(const double *rowp, const int (&co)[5], const Coeffs &cf, DST dst, int lane,
                                                      double below, double above) {
   double acc[8];
@@ -251,13 +259,26 @@ __device__ __forceinline__ void diamond25_accumulate(const double *rowp, const i
   const double *colp[5];
 #pragma unroll
   for (int d = 0; d < 5; ++d) colp[d] = rowp + co[d];
+  double v[2][13];
+  auto load = [&](int kk, double (&dstv)[13]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 13; ++q)
+      if (q < diamond_reads_of_plane(kk)) dstv[q] = colp[kDiamondPos[q].di + 2][kk * PS + kDiamondPos[q].dj * RS];
+  };
+  if (PIPELINED) load(1, v[1]);
 #pragma unroll
   for (int kk = 1; kk < 11; ++kk) {
+    if (PIPELINED) {
+      if (kk + 1 < 11) load(kk + 1, v[(kk + 1) & 1]); // the next plane's reads are in flight during this plane's arithmetic
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      load(kk, v[kk & 1]);
+    }
     const int kin = kk - 2;
 #pragma unroll
     for (int t = 0; t < 25; ++t) {
       const int k = kin - kDiamondTaps[t].dk; // output this tap of this plane feeds
-      if (k >= 0 && k < 8) acc[k] += cf.c[t] * colp[kDiamondTaps[t].di + 2][kk * PS + kDiamondTaps[t].dj * RS];
+      if (k >= 0 && k < 8) acc[k] += cf.c[t] * v[kk & 1][diamond_pos_of_tap(t)];
     }
     if (kk >= 4) store_result(&dst[(kk - 4) * 64 + lane], acc[kk - 4]); // output kk-4 has received its last plane
     __builtin_amdgcn_sched_barrier(0);
