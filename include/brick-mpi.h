@@ -1,0 +1,172 @@
+// brick-mpi.h -- BrickDecomp and friends (reference include/brick-mpi.h:178-753, src/brick-mpi.cpp:9-52) on top of the
+// layout builder of libbrk.so (brk_decomp_*): region-ordered brick numbering, ghost / skin run tables, adjacency, the
+// neighbour -> rank map, and -- when an MPI implementation is present at compile time -- the run-by-run exchange over
+// MPI (pass device pointers with a GPU-aware MPI, as weak/main.cu does).  The RCCL transports of this library live in
+// bricklib_amd/decomp.py; INTEGRATION.md shows the link tables a C++ driver builds for them.
+// Only the configuration the reference's drivers use is provided: 3 dimensions, 8x8x8 bricks, the skin3d_good section order.
+#pragma once
+
+#include <stdexcept>
+#include <unordered_map>
+#include <vector>
+
+#include "bitset.h"
+#include "brick.h"
+#include "brk.h"
+
+#if __has_include(<mpi.h>) && !defined(BRK_NO_MPI)
+#include <mpi.h>
+#define BRK_HAVE_MPI 1
+#endif
+
+// timing accumulators the reference's drivers print (src/brick-mpi.cpp:7)
+inline double packtime = 0, calltime = 0, waittime = 0, movetime = 0, calctime = 0;
+
+// all 3^dim subsets of {+-1..+-dim} with at most one sign per axis, in the reference's order (src/brick-mpi.cpp:9-23);
+// 3-D only: the order comes from the library
+inline void allneighbors(BitSet cur, long idx, long dim, std::vector<BitSet> &neighbors) {
+  if (dim != 3 || idx != 1 || cur.set != 0) throw std::runtime_error("allneighbors: only (0, 1, 3, out) is provided");
+  uint64_t raw[27];
+  brk_allneighbors3(raw);
+  for (uint64_t r : raw) neighbors.emplace_back(r);
+}
+
+template <unsigned dim, unsigned... BDims>
+class BrickDecomp {
+  static_assert(dim == 3 && sizeof...(BDims) == 3, "BrickDecomp<3, 8, 8, 8> is the provided configuration");
+
+public:
+  struct g_region {
+    BitSet neighbor;                                      // direction set of the neighbour this run talks to
+    unsigned skin_st, skin_ed, pos, len, first_pad, last_pad;
+  };
+  std::vector<g_region> ghost, skin;                      // run i: ghost[i] <- skin[i] of rank_map[ghost[i].neighbor]
+  unsigned sep_pos[3];                                    // [1,sep0) inner, [sep0,sep1) surface, [sep1,sep2) ghost
+  std::vector<BitSet> skinlist;
+  std::vector<long> skin_size;
+  std::vector<unsigned> dims, t_dims, g_depth, stride;    // in bricks: domain, domain + ghost, ghost depth, row/plane strides
+#ifdef BRK_HAVE_MPI
+  MPI_Comm comm = MPI_COMM_NULL;
+#endif
+  std::unordered_map<uint64_t, int> rank_map;             // BitSet::set -> rank, filled by populate()
+
+  BrickDecomp(const std::vector<unsigned> &dims_cells, unsigned depth_cells, unsigned numfield = 1) : numfield_(numfield) {
+    constexpr unsigned bd[3] = {BDims...};
+    if (bd[0] != 8 || bd[1] != 8 || bd[2] != 8) throw std::runtime_error("BrickDecomp: 8x8x8 bricks only");
+    if (dims_cells.size() != 3) throw std::runtime_error("BrickDecomp: three extents expected");
+    for (int a = 0; a < 3; ++a) cells_[a] = dims_cells[a];
+    depth_ = depth_cells;
+  }
+  BrickDecomp(const BrickDecomp &) = delete;
+  BrickDecomp &operator=(const BrickDecomp &) = delete;
+  ~BrickDecomp() { brk_decomp_free(h_); }
+
+  // the reference takes the order of the 26 surface sections here; the library implements skin3d_good
+  void initialize(const std::vector<BitSet> &order) {
+    if (brk_decomp_build(cells_, depth_, &h_) != BRK_OK) throw std::runtime_error(brk_last_error());
+    const uint32_t ns = brk_decomp_nskin(h_);
+    const uint64_t *sl = brk_decomp_skinlist(h_);
+    if (order.size() != ns) throw std::runtime_error("BrickDecomp::initialize: only skin3d_good is provided");
+    for (uint32_t q = 0; q < ns; ++q)
+      if (order[q].set != sl[q]) throw std::runtime_error("BrickDecomp::initialize: only skin3d_good is provided");
+    skinlist = order;
+    const int64_t *ss = brk_decomp_skin_size(h_);
+    skin_size.assign(ss, ss + ns);
+    uint32_t sp[3], td[3];
+    brk_decomp_sep_pos(h_, sp);
+    brk_decomp_tdims(h_, td);
+    for (int a = 0; a < 3; ++a) sep_pos[a] = sp[a];
+    t_dims.assign(td, td + 3);
+    dims.resize(3);
+    g_depth.assign(3, depth_ / 8);
+    stride.resize(3);
+    for (int a = 0; a < 3; ++a) dims[a] = cells_[a] / 8;
+    stride[0] = 1, stride[1] = td[0], stride[2] = td[0] * td[1];
+    const uint32_t nr = brk_decomp_nruns(h_);
+    auto conv = [](const brk_region &r) { return g_region{BitSet(r.neighbor), r.skin_st, r.skin_ed, r.pos, r.len, r.first_pad, r.last_pad}; };
+    const brk_region *g = brk_decomp_ghost(h_), *k = brk_decomp_skin(h_);
+    for (uint32_t q = 0; q < nr; ++q) ghost.push_back(conv(g[q])), skin.push_back(conv(k[q]));
+  }
+
+  // logical brick coordinates (ghost included) -> brick id: bDecomp[k][j][i]
+  struct Row {
+    const uint32_t *p;
+    unsigned operator[](int i) const { return p[i]; }
+  };
+  struct Plane {
+    const uint32_t *p;
+    unsigned t0;
+    Row operator[](int j) const { return Row{p + (size_t)j * t0}; }
+  };
+  Plane operator[](int k) const { return Plane{brk_decomp_grid(h_) + (size_t)k * t_dims[0] * t_dims[1], t_dims[0]}; }
+
+  // adjacency of every brick; the caller frees .adj as with init_grid (docs/usingbricks.md:42-47 of the reference)
+  BrickInfo<dim> getBrickInfo() const {
+    BrickInfo<dim> info(brk_decomp_nbricks(h_));
+    const uint32_t *a = brk_decomp_adj(h_);
+    unsigned *dst = &info.adj[0][0];
+    for (size_t q = 0; q < (size_t)info.nbricks * 27; ++q) dst[q] = a[q];
+    return info;
+  }
+
+  unsigned nbricks() const { return brk_decomp_nbricks(h_); }
+  const brk_decomp *handle() const { return h_; }
+
+#ifdef BRK_HAVE_MPI
+  // ghost run i <- skin run i of the rank behind ghost[i].neighbor, tag i (reference include/brick-mpi.h:466-495)
+  void exchange(BrickStorage &bStorage) {
+    std::vector<MPI_Request> req(ghost.size() * 2);
+    bElem *dat = bStorage.dat.get();
+    const size_t bytes_per_brick = bStorage.step * sizeof(bElem);
+    for (size_t q = 0; q < ghost.size(); ++q) {
+      MPI_Irecv(dat + (size_t)ghost[q].pos * bStorage.step, (int)(ghost[q].len * bytes_per_brick), MPI_CHAR,
+                rank_map[ghost[q].neighbor.set], (int)q, comm, &req[2 * q]);
+      MPI_Isend(dat + (size_t)skin[q].pos * bStorage.step, (int)(skin[q].len * bytes_per_brick), MPI_CHAR,
+                rank_map[skin[q].neighbor.set], (int)q, comm, &req[2 * q + 1]);
+    }
+    MPI_Waitall((int)req.size(), req.data(), MPI_STATUSES_IGNORE);
+  }
+#endif
+
+private:
+  brk_decomp *h_ = nullptr;
+  uint32_t cells_[3] = {0, 0, 0}, depth_ = 0;
+  unsigned numfield_;
+};
+
+// the order of the 26 surface sections the reference recommends (src/brick-mpi.cpp:25-52)
+inline const std::vector<BitSet> &skin3d_good_list() {
+  static const std::vector<BitSet> v = [] {
+    brk_decomp *h = nullptr;
+    const uint32_t c[3] = {16, 16, 16};
+    std::vector<BitSet> out;
+    if (brk_decomp_build(c, 8, &h) == BRK_OK) {
+      for (uint32_t q = 0; q < brk_decomp_nskin(h); ++q) out.emplace_back(brk_decomp_skinlist(h)[q]);
+      brk_decomp_free(h);
+    }
+    return out;
+  }();
+  return v;
+}
+#define skin3d_good (skin3d_good_list())
+
+// neighbour -> rank on a periodic Cartesian grid with MPI_Cart_rank's row-major rank order (reference populate(),
+// include/brick-mpi.h:730-753, including its orientation: the "+d" neighbour sits at coordinate - 1)
+template <unsigned dim, unsigned... BDims>
+void populate_cart(BrickDecomp<dim, BDims...> &bDecomp, const int cart_dims[3], const int coo[3]) {
+  int out[27];
+  if (brk_populate_rank_map(cart_dims, coo, out) != BRK_OK) throw std::runtime_error(brk_last_error());
+  uint64_t nb[27];
+  brk_allneighbors3(nb);
+  for (int q = 0; q < 27; ++q) bDecomp.rank_map[nb[q]] = out[q];
+}
+#ifdef BRK_HAVE_MPI
+template <unsigned dim, unsigned... BDims>
+void populate(MPI_Comm &comm, BrickDecomp<dim, BDims...> &bDecomp, BitSet neighbor, int d, int *coo) {
+  if (neighbor.set != 0 || d != 1) throw std::runtime_error("populate: call with (comm, bDecomp, 0, 1, coo)");
+  int cart[3], periods[3], mine[3];
+  MPI_Cart_get(comm, 3, cart, periods, mine);
+  bDecomp.comm = comm;
+  populate_cart(bDecomp, cart, coo);
+}
+#endif

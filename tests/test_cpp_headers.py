@@ -104,3 +104,59 @@ def test_example_driver_runs():
     assert "brick() kernel: result match" in out and "brk_stencil_apply_list: result match" in out, out
     assert "brick() cond kernel: result match" in out, out
     assert "brick() lap19 kernel (script read as data): result match" in out, out   # user-written script, generic tap path
+
+
+@pytest.mark.parametrize("dims", [(32, 24, 16), (16, 16, 16), (64, 40, 48)])
+def test_mpi_side_headers(tmp_path, dims):
+    """include/bitset.h, zmort.h and brick-mpi.h (BitSet, ZMORT, BrickDecomp<3,8,8,8>, skin3d_good, allneighbors,
+    populate_cart): a host program prints the tables it holds; they must be the Python mirror's, which is pinned against
+    fixtures produced by the reference's own headers (tests/test_host_logic.py)."""
+    import bricklib_amd as bl
+    from bricklib_amd.decomp import allneighbors, populate
+    exe = tmp_path / "probe_mpi"
+    csrc = os.path.join(ROOT, "bricklib_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "probe_mpi_headers.cpp"), "-o", str(exe), "-L", csrc, "-lbrk",
+                           "-Wl,-rpath," + csrc])
+    out = subprocess.run([str(exe)] + [str(x) for x in dims], check=True, stdout=subprocess.PIPE).stdout.decode().split("\n")
+    d = bl.BrickDecomp(dims)
+    kv = {l.split()[0]: l.split()[1:] for l in out if l and not l.startswith("run")}
+    assert int(kv["nbricks"][0]) == d.nbricks
+    assert [int(x) for x in kv["sep"]] == d.sep_pos and [int(x) for x in kv["tdims"]] == d.t_dims
+    runs = [[int(x) for x in l.split()[1:]] for l in out if l.startswith("run")]
+    assert len(runs) == len(d.ghost) == 42
+    for q, g, s in zip(range(42), d.ghost, d.skin):
+        assert runs[q] == [q, g["neighbor"], g["pos"], g["len"], g["skin_st"], g["skin_ed"], s["neighbor"], s["pos"], s["len"]]
+    h = 0
+    for v in d.grid.reshape(-1).tolist():
+        h = (h * 31 + v) % (1 << 64)
+    assert int(kv["gridhash"][0]) == h
+    h = 0
+    for v in d.adj.reshape(-1).tolist():
+        h = (h * 31 + v) % (1 << 64)
+    assert int(kv["adjhash"][0]) == h
+    rm = populate(d, [2, 2, 2], [1, 0, 1])
+    assert [int(x) for x in kv["ranks"]] == [rm[n] for n in allneighbors()]
+
+
+def test_brick_mpi_header_with_mpi(tmp_path):
+    """with an MPI implementation visible at compile time brick-mpi.h also provides populate(comm, ...) and the run-by-run
+    BrickDecomp::exchange over MPI (syntax check only: there is no MPI launcher in the test environment)"""
+    inc = next((p for p in ("/opt/conda/include", "/usr/include/x86_64-linux-gnu/mpi", "/usr/include/mpi") if os.path.exists(os.path.join(p, "mpi.h"))), None)
+    if inc is None:
+        pytest.skip("no mpi.h")
+    src = tmp_path / "mpi_probe.cpp"
+    src.write_text('''
+#include <brick-mpi.h>
+#ifndef BRK_HAVE_MPI
+#error "mpi.h not picked up"
+#endif
+void f(MPI_Comm cart, BrickStorage &st) {
+  BrickDecomp<3, 8, 8, 8> d({64, 64, 64}, 8);
+  d.initialize(skin3d_good);
+  int coo[3] = {0, 0, 0};
+  populate(cart, d, 0, 1, coo);
+  d.exchange(st);
+}
+''')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-I", inc, str(src)])
