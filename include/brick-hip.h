@@ -33,4 +33,5 @@ inline hipError_t gpuDeviceSetCacheConfig(hipFuncCache_t c) { return hipDeviceSe
 #include "brick-gpu.h"
 #if defined(__HIP__)
 #include "brick-device.h"
+#include "dev_shl.h"
 #endif

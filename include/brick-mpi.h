@@ -6,6 +6,7 @@
 // Only the configuration the reference's drivers use is provided: 3 dimensions, 8x8x8 bricks, the skin3d_good section order.
 #pragma once
 
+#include <ostream>
 #include <stdexcept>
 #include <unordered_map>
 #include <vector>
@@ -133,6 +134,31 @@ private:
   uint32_t cells_[3] = {0, 0, 0}, depth_ = 0;
   unsigned numfield_;
 };
+
+// min / avg / max / sigma of one number per rank, gathered on rank 0 (reference include/brick-mpi.h:758-793)
+struct mpi_stats {
+  double min, max, avg, sigma;
+};
+inline std::ostream &operator<<(std::ostream &os, const mpi_stats &s) {
+  return os << "[" << s.min << ", " << s.avg << ", " << s.max << "] (σ: " << s.sigma << ")";
+}
+#ifdef BRK_HAVE_MPI
+inline mpi_stats mpi_statistics(double value, MPI_Comm comm) {
+  mpi_stats out{0, 0, 0, 0};
+  if (comm == MPI_COMM_NULL) return out;
+  int size = 1;
+  MPI_Comm_size(comm, &size);
+  double sum = 0, sumsq = 0, sq = value * value;
+  MPI_Reduce(&value, &sum, 1, MPI_DOUBLE, MPI_SUM, 0, comm);
+  MPI_Reduce(&value, &out.max, 1, MPI_DOUBLE, MPI_MAX, 0, comm);
+  MPI_Reduce(&value, &out.min, 1, MPI_DOUBLE, MPI_MIN, 0, comm);
+  MPI_Reduce(&sq, &sumsq, 1, MPI_DOUBLE, MPI_SUM, 0, comm);
+  out.avg = sum / size;
+  const double var = (sumsq - sum * sum / size) / (size > 1 ? size - 1 : 1);   // sample variance
+  out.sigma = var > 0 ? __builtin_sqrt(var) : 0.0;
+  return out;
+}
+#endif
 
 // the order of the 26 surface sections the reference recommends (src/brick-mpi.cpp:25-52)
 inline const std::vector<BitSet> &skin3d_good_list() {

@@ -104,6 +104,8 @@ def test_example_driver_runs():
     assert "brick() kernel: result match" in out and "brk_stencil_apply_list: result match" in out, out
     assert "brick() cond kernel: result match" in out, out
     assert "brick() lap19 kernel (script read as data): result match" in out, out   # user-written script, generic tap path
+    out2 = subprocess.run([os.path.join(ROOT, "examples", "dev_shl_check")], check=True, stdout=subprocess.PIPE).stdout.decode()
+    assert "dev_shl: ok" in out2, out2
 
 
 @pytest.mark.parametrize("dims", [(32, 24, 16), (16, 16, 16), (64, 40, 48)])
