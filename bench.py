@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--strong-dom", type=int, default=1024)
     ap.add_argument("--strong-sub", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weak-reference", action="store_true", help="single workload: skip the extra (untimed) weak-workload line")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--schedule", default="auto", choices=("auto", "deep", "surface", "plain"),
                     help="weak workload: deep = exchange hidden behind the early passes of all sweeps, surface = behind "
@@ -432,6 +433,20 @@ def main():
     workload = args.workload or ("single" if world == 1 else "weak")
     if workload == "single":
         res, extra = run_single(args, bl, dev)
+        if not args.no_weak_reference:
+            # outside the timed region: the N > 1 workload on this one GPU (periodic self-exchange), so that the N > 1 lines of
+            # a scaling run have a like-for-like base next to the single-sweep headline
+            import copy
+            a2 = copy.copy(args)
+            a2.stencil, a2.steps, a2.warmup = None, 10, 2
+            try:
+                torch.cuda.empty_cache()
+                w, _ = run_weak(a2, bl, dev, 0, 1)
+                extra["weak_workload_on_this_gpu"] = {"value": w["cells_per_step"] * w["K"] / w["wall"] / 1e9, "unit": "GStencil/s",
+                                                      "ms_per_step": w["wall"] / w["K"] * 1e3, "workload": w["workload"],
+                                                      "updates_per_pass": w["updates_per_pass"], "schedule": w["schedule"]}
+            except Exception as e:
+                extra["weak_workload_on_this_gpu"] = {"error": repr(e)}
     elif workload == "strong":
         res, extra = run_strong(args, bl, dev, rank, world)
     else:

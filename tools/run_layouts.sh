@@ -4,7 +4,7 @@ set -o pipefail
 mkdir -p gpurun_out/layouts
 for lay in separate interleaved; do
   for st in 7pt mpi7pt mpi13pt mpi25pt 27pt mpi125pt; do
-    timeout -k 10 300 python bench.py --stencil $st --layout $lay --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/layouts/${lay}_$st.json 2> gpurun_out/layouts/${lay}_$st.err
+    timeout -k 10 300 python bench.py --stencil $st --layout $lay --steps 100 --warmup 10 --no-cpu-baseline --no-weak-reference > gpurun_out/layouts/${lay}_$st.json 2> gpurun_out/layouts/${lay}_$st.err
     rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "$st killed"; exit 1; fi
   done
 done
