@@ -399,14 +399,15 @@ def run_strong(args, bl, dev, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     sum1 = global_sum()
-    drift = abs(sum1 - sum0) / abs(sum0) if name in ("mpi7pt", "mpi13pt", "mpi25pt", "mpi125pt") else None
-    cells = float(args.strong_dom) ** 3 * S
+    drift = abs(sum1 - sum0) / abs(sum0) if name in ("mpi7pt", "mpi13pt", "mpi25pt", "mpi125pt", "mpi7pt_x2") else None
+    upd = 2 if name.endswith("_x2") else 1
+    cells = float(args.strong_dom) ** 3 * S * upd
     local_cells = float(args.strong_sub) ** 3 * sr.nsub
     res = {"workload": f"strong-{name}-{args.strong_dom}-{args.strong_sub}", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * local_cells,
            "kernel": "%s sweeps over %d subdomains of %d^3 (+ghost) per rank, one launch per sweep; kernel_ms = step / %d"
                      % (name, sr.nsub, args.strong_sub, S),
-           "scaling": "strong", "conservation_rel_drift": drift, "cells_per_gpu": int(local_cells), "subdomains_per_rank": sr.nsub, "remote_bytes_per_rank": sr.bytes_remote}
+           "scaling": "strong", "updates_per_pass": upd, "conservation_rel_drift": drift, "cells_per_gpu": int(local_cells), "subdomains_per_rank": sr.nsub, "remote_bytes_per_rank": sr.bytes_remote}
     return res, {}
 
 
