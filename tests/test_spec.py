@@ -61,3 +61,25 @@ STENCIL = [v]
 def test_unsupported_scripts_are_reported(body, msg):
     with pytest.raises(ValueError, match=msg):
         load_spec(HEAD + "from st.func import Func\nfrom st.expr import If\n" + body)
+
+
+def test_oracle_tap_evaluation_agrees_with_pinned_stencils(oracle):
+    """orc_brick_taps (the checker of the generic tap path) against the oracle's own 7- and 13-point brick stencils, which
+    are pinned bit-exactly against the reference (tests/test_oracle_golden.py): same numbers up to the order of additions."""
+    import numpy as np
+    from oracle.oracle import ST_7PT_COEFF, ST_MPI13
+    dims = (5, 5, 5)
+    grid, adj = oracle.init_grid(dims)
+    rng = np.random.default_rng(4)
+    hin = rng.random(adj.shape[0] * 512)
+    ids = np.array([grid.reshape(5, 5, 5)[2, 2, 2], grid.reshape(5, 5, 5)[2, 1, 3]], dtype=np.uint32)
+    coeff = oracle.coeffs(129, 1)
+    seven = [((0, 0, 0), coeff[0]), ((1, 0, 0), coeff[1]), ((-1, 0, 0), coeff[2]), ((0, 1, 0), coeff[3]), ((0, -1, 0), coeff[4]),
+             ((0, 0, 1), coeff[5]), ((0, 0, -1), coeff[6])]
+    s = load_spec(star_script(2, ["MPI_B0", "MPI_B1", "MPI_B2"]))
+    thirteen = s.taps({"MPI_B0": 0.4, "MPI_B1": 0.07, "MPI_B2": 0.03})
+    for sid, taps, c in ((ST_7PT_COEFF, seven, coeff), (ST_MPI13, thirteen, None)):
+        a, b = np.zeros_like(hin), np.zeros_like(hin)
+        oracle.brick_stencil(sid, adj, hin, a, 512, ids=ids, coeff=c)
+        oracle.brick_taps(adj, hin, b, 512, ids, taps)
+        assert np.abs(a - b).max() <= 1e-14 and np.abs(b).max() > 0
