@@ -58,7 +58,7 @@ enum { BRK_7PT_COEFF = 0, BRK_27PT_COEFF = 1, BRK_MPI7 = 2, BRK_MPI13 = 3, BRK_M
        BRK_MPI7_X2 = 7, BRK_7PT_X2 = 8, BRK_NSTENCIL = 9 };
 
 const char *brk_last_error(void);
-/* 7*1000+... style version of this ABI */
+/* version of this ABI: 1000 + additions (1001: brk_stencil_apply_taps, 1002: the fused double-sweep stencil ids) */
 int brk_abi_version(void);
 /* radius / number of coefficients / communication-avoiding sweeps per exchange (ST_ITER, fake.h:39-344) */
 int brk_stencil_radius(int stencil_id);
