@@ -25,7 +25,7 @@ int brk_fail(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *brk_last_error(void) { return g_err; }
-extern "C" int brk_abi_version(void) { return 1002; } // 1001: brk_stencil_apply_taps; 1002: BRK_MPI7_X2, BRK_7PT_X2
+extern "C" int brk_abi_version(void) { return 1003; } // 1001: brk_stencil_apply_taps; 1002: BRK_MPI7_X2, BRK_7PT_X2; 1003: exchange
 
 // ---------------------------------------------------------------------------------------------- stencil facts
 extern "C" int brk_stencil_radius(int id) {
@@ -45,32 +45,13 @@ extern "C" int brk_stencil_iters(int id) {
 
 // ---------------------------------------------------------------------------------------------- direction sets
 // A direction set is the reference's BitSet (include/bitset.h:20-30): axis p in 1..3, "+p" is bit p, "-p" is
-// bit 31+p.  Negating all directions swaps the two halves (bitset.h:119-126).
+// bit 31+p.  Negating all directions swaps the two halves (bitset.h:119-126).  Helpers: brk_internal.h.
+using namespace brk_dir;
 namespace {
-inline uint64_t dir_bit(int p) { return 1ull << (p > 0 ? p : 31 - p); }
-inline bool has(uint64_t s, int p) { return (s & dir_bit(p)) != 0; }
-inline uint64_t negate(uint64_t s) { return ((s & 0xFFFFFFFFull) << 31) | (s >> 31); }
-inline bool contains(uint64_t big, uint64_t small) { return (big & small) == small; }
-
 uint64_t make_set(std::initializer_list<int> l) {
   uint64_t s = 0;
   for (int p : l) s ^= dir_bit(p);
   return s;
-}
-
-// src/brick-mpi.cpp:9-23 -- for axis 1,2,3 in turn choose '+', nothing, '-' (axis 1 varies slowest).
-void neighbors3(std::array<uint64_t, 27> &out) {
-  int q = 0;
-  const int pick[3] = {+1, 0, -1};
-  for (int a : pick)
-    for (int b : pick)
-      for (int c : pick) {
-        uint64_t s = 0;
-        if (a) s |= dir_bit(a * 1);
-        if (b) s |= dir_bit(b * 2);
-        if (c) s |= dir_bit(c * 3);
-        out[q++] = s;
-      }
 }
 
 // src/brick-mpi.cpp:25-52 (skin3d_good): the order in which the 26 surface sections are laid out.
@@ -85,6 +66,21 @@ const std::vector<uint64_t> &surface_order() {
   return v;
 }
 } // namespace
+
+// src/brick-mpi.cpp:9-23 -- for axis 1,2,3 in turn choose '+', nothing, '-' (axis 1 varies slowest).
+void brk_dir::neighbors3(std::array<uint64_t, 27> &out) {
+  int q = 0;
+  const int pick[3] = {+1, 0, -1};
+  for (int a : pick)
+    for (int b : pick)
+      for (int c : pick) {
+        uint64_t s = 0;
+        if (a) s |= dir_bit(a * 1);
+        if (b) s |= dir_bit(b * 2);
+        if (c) s |= dir_bit(c * 3);
+        out[q++] = s;
+      }
+}
 
 extern "C" void brk_allneighbors3(uint64_t out[27]) {
   std::array<uint64_t, 27> a;
@@ -125,15 +121,6 @@ extern "C" int brk_init_grid(const long dims[3], uint32_t *grid, uint32_t *adj) 
 //   [sep1, sep2)   ghost: per neighbour n, the sections of n's surface that contain -n, in the same order (:404-452)
 // id 0 is a dummy brick that every out-of-domain adjacency entry points to (:275-276,:353).
 // Brick size (4096 B) equals the page size, so the page-padding logic (:342-368) contributes nothing.
-struct brk_decomp {
-  uint32_t dims[3], tdims[3], depth[3], stride[3];
-  uint32_t sep[3];
-  uint32_t nbricks;
-  std::vector<uint32_t> grid, adj;
-  std::vector<uint64_t> skinlist;
-  std::vector<int64_t> skin_size;
-  std::vector<brk_region> ghost, skin;
-};
 
 namespace {
 // Number the bricks of section `region` of the subdomain displaced by `owner` (0 = ours), k slowest, i fastest.
@@ -251,7 +238,14 @@ extern "C" int brk_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cel
   return BRK_OK;
 }
 
-extern "C" void brk_decomp_free(brk_decomp *d) { delete d; }
+extern "C" void brk_decomp_free(brk_decomp *d) {
+  if (!d) return;
+  for (auto &e : d->xcache) { // what brk_exchange() built for this decomposition
+    brk_exchange_view_free(e.view);
+    brk_xplan_free(e.plan);
+  }
+  delete d;
+}
 extern "C" uint32_t brk_decomp_nbricks(const brk_decomp *d) { return d->nbricks; }
 extern "C" uint32_t brk_decomp_grid_size(const brk_decomp *d) { return (uint32_t)d->grid.size(); }
 extern "C" void brk_decomp_tdims(const brk_decomp *d, uint32_t out[3]) { std::copy(d->tdims, d->tdims + 3, out); }

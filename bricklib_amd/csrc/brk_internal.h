@@ -6,4 +6,40 @@
 // records the message for brk_last_error() and returns `code`
 int brk_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+#ifdef __cplusplus
+#include <array>
+#include <mutex>
+#include <vector>
+
+// direction sets = the reference's BitSet (include/bitset.h:20-30): axis p in 1..3, "+p" is bit p, "-p" is bit 31+p
+namespace brk_dir {
+inline uint64_t dir_bit(int p) { return 1ull << (p > 0 ? p : 31 - p); }
+inline bool has(uint64_t s, int p) { return (s & dir_bit(p)) != 0; }
+inline uint64_t negate(uint64_t s) { return ((s & 0xFFFFFFFFull) << 31) | (s >> 31); }
+inline bool contains(uint64_t big, uint64_t small) { return (big & small) == small; }
+void neighbors3(std::array<uint64_t, 27> &out); // src/brick-mpi.cpp:9-23 order
+} // namespace brk_dir
+
+// plan + view that brk_exchange() built for one (storage, step, rank map, communicator)
+struct brk_xcache_entry {
+  void *storage, *comm;
+  size_t step;
+  int ranks[27];
+  brk_xplan *plan;
+  brk_exchange_view *view;
+};
+
+struct brk_decomp {
+  uint32_t dims[3], tdims[3], depth[3], stride[3];
+  uint32_t sep[3];
+  uint32_t nbricks;
+  std::vector<uint32_t> grid, adj;
+  std::vector<uint64_t> skinlist;
+  std::vector<int64_t> skin_size;
+  std::vector<brk_region> ghost, skin;
+  std::mutex xmu;
+  std::vector<brk_xcache_entry> xcache;
+};
+#endif
+
 #endif

@@ -11,6 +11,7 @@
 //     block id is remapped to give each XCD one contiguous eighth of the list; consecutive bricks (which share
 //     faces) then meet in the same 4 MiB L2.
 // HBM-bound by design: 16 B of compulsory traffic per lattice update, no MFMA (not a contraction).
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -152,7 +153,9 @@ __global__ __launch_bounds__(kWG) void k_iter(IterGeom g, double *__restrict__ a
   }
 }
 
-int g_variant[BRK_NSTENCIL] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+// experiment knob (brk_set_variant): read once per launch; atomic so that a concurrent setter is not a data race, but a
+// process that changes variants while other threads launch gets either kernel -- documented as not thread-safe in brk.h
+std::atomic<int> g_variant[BRK_NSTENCIL];
 constexpr int kDefaultStar7Variant = 5; // 8-wave workgroups sharing i-faces through LDS (brk_star7.hip)
 
 // defaults: stencils/fake.h:11-33
@@ -210,22 +213,23 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   if (in == out) return brk_fail(BRK_EINVAL, "in and out must be different fields");
   if (step < 512) return brk_fail(BRK_EINVAL, "step_elems %zu < 512", step);
   if (n == 0) return BRK_OK;
+  const int var = g_variant[id].load(std::memory_order_relaxed);
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
   const uint32_t wgs = (n + kWavesPerWG - 1) / kWavesPerWG;
   const dim3 grid(((wgs + 7) / 8) * 8), block(kWG);
   hipStream_t st = static_cast<hipStream_t>(s);
   // 7-point sweeps: specialised kernels (brk_star7.hip) unless variant 1 (generic star kernel) is requested
-  if ((id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) && g_variant[id] != 1)
-    return launch_star7(id, g_variant[id] == 0 ? kDefaultStar7Variant : g_variant[id], adj, in, out, step, ids, first, n, cf, st);
-  if ((id == BRK_MPI13 || id == BRK_MPI25) && g_variant[id] != 1) return launch_star_wg(id, g_variant[id], adj, in, out, step, ids, first, n, cf, st);
+  if ((id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) && var != 1)
+    return launch_star7(id, var == 0 ? kDefaultStar7Variant : var, adj, in, out, step, ids, first, n, cf, st);
+  if ((id == BRK_MPI13 || id == BRK_MPI25) && var != 1) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st);
   // 27/125-pt: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip) by default; variant 1 = generic
   // one-wave kernel, 27-pt variant 2 and 125-pt variants 2/4/8 = padded tiles with shared i-halos (brk_cubewg.hip),
   // 125-pt variant 3 = generic kernel with 4 waves per workgroup.  Measured at 512^3 (profiles/): 27-pt 0.555 (padded,
   // 8 waves) -> 0.43 ms; 125-pt 1.06 (generic) -> 0.70 ms.
-  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, g_variant[id], adj, in, out, step, ids, first, n, cf, st);
+  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
-    const int v = g_variant[id];
+    const int v = var;
     if (v == 0 || (v >= 5 && v <= 9)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st);
     if ((id == BRK_27PT_COEFF && v == 2) || (id == BRK_MPI125 && (v == 2 || v == 4 || v == 8)))
       return launch_cube_wg(id, id == BRK_MPI125 ? v : 8, adj, in, out, step, ids, first, n, cf, st);
@@ -238,7 +242,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   case BRK_MPI25: hipLaunchKernelGGL(k_star<kStarMpi25>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_27PT_COEFF: hipLaunchKernelGGL((k_cube<kCube27, 4>), grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_MPI125:
-    if (g_variant[id] == 3)
+    if (var == 3)
       hipLaunchKernelGGL((k_cube<kCube125, 4>), grid, block, 0, st, adj, in, out, step, ids, first, n, cf);
     else // variant 1
       hipLaunchKernelGGL((k_cube<kCube125, 1>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, cf);
@@ -280,27 +284,35 @@ extern "C" int brk_set_variant(int id, int v) {
 
 // Id list of a structured box in the traversal order of bricklib_amd/order.py (per-XCD slabs of j-rows swept over all k,
 // left-over rows cut along k, one skipped entry behind rows that are not a multiple of 8, XCD parts padded to equal length).
-// Lists are owned by the library: a small per-process cache keyed by the geometry, least recently used entry replaced.
+// Lists are owned by the library: a small per-process cache keyed by (device, geometry), least recently used entry replaced.
+// Lifetime rules (brk.h promises thread safety for distinct streams and devices):
+//   * the cache mutex is held from the lookup until the launch that reads the list has been enqueued and an event has been
+//     recorded behind it on the launch stream -- another thread cannot replace the entry in between;
+//   * a replaced list is not freed in place: it waits for its last reader's event (that stream only, no device-wide
+//     synchronisation) and is released on the device that owns it.
 struct BoxList {
-  uint32_t key[10];
+  uint32_t key[11];
   uint32_t *dev;
   uint32_t n;
   uint64_t stamp;
+  int device;
+  hipEvent_t last_use; // recorded behind the most recent launch that reads `dev`
 };
-constexpr int kBoxCache = 8;
+constexpr int kBoxCache = 16;
 BoxList g_box[kBoxCache];
 uint64_t g_box_clock = 0;
 std::mutex g_box_mutex;
 
-int box_list(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const uint32_t **ids, uint32_t *n) {
-  std::lock_guard<std::mutex> lock(g_box_mutex);
-  const uint32_t key[10] = {base, tot[0], tot[1], tot[2], lo[0], lo[1], lo[2], cnt[0], cnt[1], cnt[2]};
+// caller holds g_box_mutex
+int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], BoxList **entry) {
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  const uint32_t key[11] = {(uint32_t)device, base, tot[0], tot[1], tot[2], lo[0], lo[1], lo[2], cnt[0], cnt[1], cnt[2]};
   int victim = 0;
   for (int q = 0; q < kBoxCache; ++q) {
     if (g_box[q].dev && std::memcmp(g_box[q].key, key, sizeof key) == 0) {
       g_box[q].stamp = ++g_box_clock;
-      *ids = g_box[q].dev;
-      *n = g_box[q].n;
+      *entry = &g_box[q];
       return BRK_OK;
     }
     if (g_box[q].stamp < g_box[victim].stamp) victim = q;
@@ -328,17 +340,28 @@ int box_list(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const u
   for (uint32_t x = 0; x < 8; ++x) std::copy(part[x].begin(), part[x].end(), host.begin() + x * per);
   BoxList &e = g_box[victim];
   if (e.dev) {
-    HIP_TRY(hipDeviceSynchronize()); // a launch still reading the list we are about to replace
-    HIP_TRY(hipFree(e.dev));
+    // retire the replaced list on its own device once its last reader has finished
+    if (e.device != device) HIP_TRY(hipSetDevice(e.device));
+    hipError_t r = hipEventSynchronize(e.last_use);
+    if (r == hipSuccess) r = hipFree(e.dev);
+    if (r == hipSuccess) r = hipEventDestroy(e.last_use);
+    if (e.device != device) HIP_TRY(hipSetDevice(device));
+    HIP_TRY(r);
     e.dev = nullptr;
   }
   HIP_TRY(hipMalloc(&e.dev, host.size() * sizeof(uint32_t)));
-  HIP_TRY(hipMemcpy(e.dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  hipError_t r = hipMemcpy(e.dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (r == hipSuccess) r = hipEventCreateWithFlags(&e.last_use, hipEventDisableTiming);
+  if (r != hipSuccess) {
+    (void)hipFree(e.dev);
+    e.dev = nullptr;
+    HIP_TRY(r);
+  }
   std::memcpy(e.key, key, sizeof key);
   e.n = (uint32_t)host.size();
+  e.device = device;
   e.stamp = ++g_box_clock;
-  *ids = e.dev;
-  *n = e.n;
+  *entry = &e;
   return BRK_OK;
 }
 
@@ -399,10 +422,12 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
   if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7)
     return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s));
   // other stencils: the same traversal order as an id list, built once per box geometry and kept on the device
-  const uint32_t *ids = nullptr;
-  uint32_t n = 0;
-  if (int rc = box_list(base, tot, lo, cnt, &ids, &n)) return rc;
-  return launch_stencil(id, adj, in, out, step, ids, 0, n, coeff_host, s);
+  std::lock_guard<std::mutex> lock(g_box_mutex);
+  BoxList *e = nullptr;
+  if (int rc = box_list_locked(base, tot, lo, cnt, &e)) return rc;
+  if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s)) return rc;
+  HIP_TRY(hipEventRecord(e->last_use, static_cast<hipStream_t>(s)));
+  return BRK_OK;
 }
 
 extern "C" int brk_link_copy(const brk_link *links, uint32_t n, uint64_t max_bytes, brk_stream s) {

@@ -37,7 +37,8 @@ enum {
   BRK_EINVAL = -1,   /* bad argument (null pointer, unknown stencil id, misaligned/size mismatch) */
   BRK_EHIP = -2,     /* a HIP runtime call failed; brk_last_error() carries hipGetErrorString */
   BRK_ENOMEM = -3,
-  BRK_ENODEV = -4    /* no gfx950 device / code object could not be loaded */
+  BRK_ENODEV = -4,   /* no gfx950 device / code object could not be loaded */
+  BRK_ECOMM = -5     /* an RCCL call failed, or librccl could not be loaded; brk_last_error() carries ncclGetErrorString */
 };
 
 /* Stencils on the path.  Coefficient vectors (host memory, doubles):
@@ -58,7 +59,8 @@ enum { BRK_7PT_COEFF = 0, BRK_27PT_COEFF = 1, BRK_MPI7 = 2, BRK_MPI13 = 3, BRK_M
        BRK_MPI7_X2 = 7, BRK_7PT_X2 = 8, BRK_NSTENCIL = 9 };
 
 const char *brk_last_error(void);
-/* version of this ABI: 1000 + additions (1001: brk_stencil_apply_taps, 1002: the fused double-sweep stencil ids) */
+/* version of this ABI: 1000 + additions (1001: brk_stencil_apply_taps, 1002: the fused double-sweep stencil ids,
+ * 1003: the ghost-zone exchange: brk_xplan_*, brk_exchange_*, brk_comm_*) */
 int brk_abi_version(void);
 /* radius / number of coefficients / communication-avoiding sweeps per exchange (ST_ITER, fake.h:39-344) */
 int brk_stencil_radius(int stencil_id);
@@ -101,7 +103,8 @@ int brk_stencil_apply_box(int stencil_id, const uint32_t *adj_dev, const double 
 int brk_stencil_apply_taps(const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
                            const uint32_t *brick_ids_dev, uint32_t first, uint32_t n, uint32_t ntaps,
                            const int32_t *offsets_host, const double *weights_host, brk_stream s);
-/* Kernel variant selection for experiments/benchmarks: 0 = default. */
+/* Kernel variant selection for experiments/benchmarks: 0 = default.  A process-wide knob, NOT thread-safe with respect to
+ * concurrent launches (a launch racing with a setter runs either variant; every variant computes the same result). */
 int brk_set_variant(int stencil_id, int variant);
 
 /* ---- region copies: pack / unpack / same-GPU halo links --------------------------------------------------------
@@ -162,6 +165,92 @@ void brk_allneighbors3(uint64_t out[27]);
 int brk_populate_rank_map(const int cart_dims[3], const int coo[3], int out[27]);
 /* MPI_Dims_create(size,3) as used by weak/args.cpp:105 for sizes whose prime factors are 2,3,5,7 */
 int brk_dims_create(int size, int out[3]);
+
+/* ---- ghost-zone exchange: GPU-resident pack / unpack feeding RCCL send/recv ------------------------------------------
+ * Replaces BrickDecomp::exchange (include/brick-mpi.h:466-495), ExchangeView::exchange (:82-123),
+ * MultiStageExchangeView::exchange (:131-165, built at :587-681) and the strong driver's pack -> MPI -> unpack
+ * (strong/main.cu:367-482), with the MPI messages replaced by ncclSend/ncclRecv in one group on the caller's stream.
+ *
+ * A PLAN is host-side bookkeeping only (offsets, sizes, peers): which byte ranges are copied where before the transport
+ * ("begin": same-GPU links and packing), which messages travel, and which copies follow ("end": unpacking), per stage
+ * (one stage, or three for the shift exchange).  A VIEW binds a plan to one storage on the current device (the reference's
+ * ExchangeView): it owns the per-peer send/recv buffers and the device-resident brk_link tables.
+ * Three "spaces" name where a byte range lives: the brick storage, or the send / receive buffer kept for one peer. */
+enum { BRK_SP_STORAGE = 0, BRK_SP_SEND = 1, BRK_SP_RECV = 2 };
+typedef struct {
+  uint32_t stage;
+  uint32_t phase;              /* 0 = begin (before the transport), 1 = end (after it) */
+  uint32_t src_space, dst_space;
+  int32_t src_peer, dst_peer;  /* rank whose send/recv buffer is meant; -1 for BRK_SP_STORAGE */
+  uint64_t src_off, dst_off, bytes; /* byte offsets inside the space; multiples of 16 */
+} brk_xcopy;
+typedef struct {
+  uint32_t stage;
+  uint32_t is_send;            /* 1 = ncclSend to `peer`, 0 = ncclRecv from `peer` */
+  int32_t peer;
+  uint32_t space;              /* BRK_SP_STORAGE (zero-copy run, the reference's form) or BRK_SP_SEND / BRK_SP_RECV (packed) */
+  uint64_t off, bytes;
+} brk_xmsg;
+typedef struct brk_xplan brk_xplan;
+typedef struct brk_exchange_view brk_exchange_view;
+
+/* mode: how the ghost runs of a BrickDecomp that leave this rank travel.
+ *  BRK_XCHG_PACKED  everything bound for one peer is packed into one buffer: ONE send + ONE recv per peer (<= 7 peers on a
+ *                   2x2x2 grid), unpacked by one launch -- few, large xGMI transfers (default of the drivers)
+ *  BRK_XCHG_DIRECT  one message per run straight from / into the storage, <= 42 per exchange (brick-mpi.h:476-484)
+ *  BRK_XCHG_SHIFT   three stages, one per axis, each trading two boundary layers that span the ghosts received in the earlier
+ *                   stages: <= 2 messages per stage (MultiStageExchangeView, brick-mpi.h:587-681)
+ * flags: BRK_XCHG_SELF_VIA_COMM sends runs whose peer is this rank through the communicator too (ncclSend to self) instead of
+ *        as device links -- for exercising the transport on a single GPU. */
+enum { BRK_XCHG_PACKED = 0, BRK_XCHG_DIRECT = 1, BRK_XCHG_SHIFT = 2 };
+enum { BRK_XCHG_SELF_VIA_COMM = 1u };
+/* rank_of_neighbor[27] is indexed like brk_allneighbors3 (what brk_populate_rank_map writes; the reference's rank_map). */
+int brk_xplan_build_decomp(const brk_decomp *d, const int rank_of_neighbor[27], int my_rank, int mode, unsigned flags,
+                           size_t step_elems, brk_xplan **out);
+/* a plan from explicit tables (the strong driver builds its own: several subdomains per rank, strong/main.cu:188-395);
+ * copies and messages are taken in the given order, which both ends must agree on */
+int brk_xplan_build_tables(int my_rank, uint32_t ncopies, const brk_xcopy *copies, uint32_t nmsgs, const brk_xmsg *msgs,
+                           brk_xplan **out);
+void brk_xplan_free(brk_xplan *p);
+int brk_xplan_my_rank(const brk_xplan *p);
+uint32_t brk_xplan_nstages(const brk_xplan *p);
+uint32_t brk_xplan_ncopies(const brk_xplan *p);
+const brk_xcopy *brk_xplan_copies(const brk_xplan *p);
+uint32_t brk_xplan_nmsgs(const brk_xplan *p);
+const brk_xmsg *brk_xplan_msgs(const brk_xplan *p);
+/* bytes per exchange that leave the rank (sum of the sends) / that are copied inside it by the begin+end launches */
+uint64_t brk_xplan_bytes_remote(const brk_xplan *p);
+uint64_t brk_xplan_bytes_local(const brk_xplan *p);
+/* size of the send (which = BRK_SP_SEND) or receive buffer kept for `peer` in `stage`; 0 if there is none */
+uint64_t brk_xplan_buffer_bytes(const brk_xplan *p, uint32_t stage, int peer, uint32_t which);
+
+/* bind to a storage on the current device: allocates the buffers and uploads the link tables (synchronous) */
+int brk_exchange_view_create(const brk_xplan *p, void *storage_dev, brk_exchange_view **out);
+void brk_exchange_view_free(brk_exchange_view *v);
+/* the three steps of one stage, each asynchronous on `s`:  begin = links + pack (one brk_link_copy launch),
+ * transport = ncclGroupStart; ncclRecv/ncclSend per message; ncclGroupEnd  on `nccl_comm` (an ncclComm_t),
+ * end = unpack (one launch).  brk_exchange_run does all stages in order. */
+int brk_exchange_begin(brk_exchange_view *v, uint32_t stage, brk_stream s);
+int brk_exchange_transport(brk_exchange_view *v, uint32_t stage, void *nccl_comm, brk_stream s);
+int brk_exchange_end(brk_exchange_view *v, uint32_t stage, brk_stream s);
+int brk_exchange_run(brk_exchange_view *v, void *nccl_comm, brk_stream s);
+/* transport between views that live on ONE GPU (several virtual ranks per GPU): every message of `stage` sent by
+ * views[a] to the rank of views[b] is copied into the matching receive of views[b] (device copies on `s`, message order as
+ * in the plans).  All views must come from plans of the same decomposition and mode. */
+int brk_exchange_loopback(brk_exchange_view *const *views, uint32_t nviews, uint32_t stage, brk_stream s);
+/* device address of a view's send / receive buffer for `peer` (NULL if none): for transports outside this library */
+void *brk_exchange_view_buffer(const brk_exchange_view *v, uint32_t stage, int peer, uint32_t which);
+/* The reference signature: exchange the ghosts of `storage_dev` over `nccl_comm`; this rank is
+ * ncclCommUserRank(comm).  Packed mode; the plan and view are built on first use and kept inside the brk_decomp. */
+int brk_exchange(brk_decomp *d, double *storage_dev, size_t step_elems, void *nccl_comm, const int rank_of_neighbor[27],
+                 brk_stream s);
+
+/* RCCL communicators without MPI or torch in the loop (librccl is loaded on first use).  id128 = ncclUniqueId (128 bytes):
+ * rank 0 calls brk_comm_unique_id and hands the bytes to the others (MPI_Bcast, a file, torch.distributed, ...). */
+int brk_comm_unique_id(void *id128);
+int brk_comm_init_rank(void **nccl_comm, int nranks, const void *id128, int rank);
+int brk_comm_destroy(void *nccl_comm);
+int brk_comm_rank(void *nccl_comm, int *rank, int *nranks);
 
 /* Strong scaling bookkeeping (include/zmort.h:18-105, strong/args.cpp:36-56,104-113) */
 uint64_t brk_zmort_get(uint64_t id, uint64_t d);

@@ -347,46 +347,73 @@ def test_padded_tiled_lists_all_stencils(oracle, dev, name):
     assert np.abs(so.dat.cpu().numpy() - want).max() <= TOL
 
 
-@pytest.mark.parametrize("name", ["7pt", "mpi13pt", "27pt"])
-def test_full_size_512_properties(oracle, dev, name):
-    """BASELINE size (512^3, 262144 bricks): size-independent properties + a sampled comparison with the oracle.
+# sum of the weights of every stencil with fixed coefficients (stencils/fake.h:11-33; 125-pt: class weight x multiplicity)
+_C125 = (0.1, 0.04, 0.03, 0.01, 0.006, 0.004, 0.005, 0.002, 0.003, 0.001)
+_M125 = (1, 6, 6, 12, 24, 12, 8, 24, 24, 8)     # points per class sorted(|di|,|dj|,|dk|) = 000 001 002 011 012 022 111 112 122 222
+WSUM = {"mpi7pt": 0.4 + 6 * 0.1, "mpi13pt": 0.4 + 6 * 0.07 + 6 * 0.03, "mpi25pt": 0.1 + 6 * (0.06 + 0.045 + 0.03 + 0.015),
+        "mpi125pt": sum(c * m for c, m in zip(_C125, _M125)), "mpi7pt_x2": (0.4 + 6 * 0.1) ** 2}
+
+
+@pytest.mark.parametrize("name", ["7pt", "mpi7pt", "mpi13pt", "mpi25pt", "27pt", "mpi125pt", "mpi7pt_x2"])
+@pytest.mark.parametrize("form", ["list", "box"])
+def test_full_size_512_properties(oracle, dev, name, form):
+    """BASELINE size (512^3, 262144 bricks), every stencil of configs 2-4 (7-pt; 27-pt + 125-pt; the weak driver's mpi7pt and
+    its fused double sweep; 13/25-pt), through the list entry point and the reference's box launch shape:
       * linearity  S(a*x + b*y) == a*S(x) + b*S(y)
       * a constant field maps to (sum of weights) * constant
-      * 1024 random bricks agree with the CPU oracle."""
+      * 1024 random bricks agree with the CPU oracle (the fused pass: with two oracle sweeps)."""
     from bricklib_amd.order import tiled
     N, SB = 512, 66
     grid, info = bl.init_grid((SB, SB, SB), dev)
-    ids = tiled(grid.reshape(SB, SB, SB)[1:-1, 1:-1, 1:-1])
+    g3 = grid.reshape(SB, SB, SB)
+    ids = tiled(g3[1:-1, 1:-1, 1:-1])
     ids_dev = grid_to_device(ids, dev)
     coeff = oracle.coeffs(129, 1) if name in ("7pt", "27pt") else None
     x, y, sx, sy, sz = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(5))
     x.dat.uniform_(0.0, 1.0)
     y.dat.uniform_(0.0, 1.0)
     B = lambda s: bl.Brick(info, s, 0)
-    bl.apply_stencil(name, B(x), B(sx), ids=ids_dev, coeff=coeff)
-    bl.apply_stencil(name, B(y), B(sy), ids=ids_dev, coeff=coeff)
+    NB = SB - 2
+    where = dict(box=(0, (SB, SB, SB), (1, 1, 1), (NB, NB, NB))) if form == "box" else dict(ids=ids_dev)
+    bl.apply_stencil(name, B(x), B(sx), coeff=coeff, **where)
+    bl.apply_stencil(name, B(y), B(sy), coeff=coeff, **where)
     a, b = 0.75, -1.25
     z = bl.BrickStorage(a * x.dat + b * y.dat, info.nbricks, 512)
-    bl.apply_stencil(name, B(z), B(sz), ids=ids_dev, coeff=coeff)
+    bl.apply_stencil(name, B(z), B(sz), coeff=coeff, **where)
     lin = (sz.dat - (a * sx.dat + b * sy.dat)).abs().max().item()
     assert lin <= 1e-12, lin
     # constant field
     z.dat.fill_(2.5)
-    bl.apply_stencil(name, B(z), B(sz), ids=ids_dev, coeff=coeff)
+    bl.apply_stencil(name, B(z), B(sz), coeff=coeff, **where)
     if name == "7pt":
         wsum = coeff[:7].sum()
     elif name == "27pt":
         wsum = coeff[:27].sum()      # the quirk moves coeff[16] to another tap, the sum is unchanged
     else:
-        wsum = 0.4 + 6 * 0.07 + 6 * 0.03
-    inner = sz.dat.view(-1, 512)[torch.from_numpy(ids.astype(np.int64)).to(dev)]
+        wsum = WSUM[name]
+    real = ids[ids != 0xFFFFFFFF]
+    inner = sz.dat.view(-1, 512)[torch.from_numpy(real.astype(np.int64)).to(dev)]
     assert (inner - 2.5 * wsum).abs().max().item() <= 1e-12
+    # bricks outside the swept box are untouched (sx started as zeros)
+    mask = torch.ones(info.nbricks, dtype=torch.bool, device=dev)
+    mask[torch.from_numpy(real.astype(np.int64)).to(dev)] = False
+    assert (sx.dat.view(-1, 512)[mask] == 0).all()
     # sampled bricks vs oracle
     rng = np.random.default_rng(3)
-    sub = np.sort(rng.choice(ids, 1024, replace=False)).astype(np.uint32)
     hin = x.dat.cpu().numpy()
     want = np.zeros_like(hin)
-    oracle.brick_stencil(NAMES[name], info.adj_host, hin, want, 512, ids=sub, coeff=coeff)
+    if name.endswith("_x2"):
+        # two oracle sweeps: the first over the sample's 27-brick neighbourhoods, the second over the sample itself, which
+        # is drawn two bricks inside the box so that no first-sweep brick reads outside the grid
+        sub = np.sort(rng.choice(np.ascontiguousarray(g3[3:-3, 3:-3, 3:-3]).reshape(-1), 256, replace=False)).astype(np.uint32)
+        ring = np.unique(info.adj_host[sub].reshape(-1)).astype(np.uint32)
+        mid = np.zeros_like(hin)
+        oracle.brick_stencil(NAMES[name[:-3]], info.adj_host, hin, mid, 512, ids=ring, coeff=coeff)
+        # outside `ring` the first sweep is unknown; the second sweep of `sub` only reads `ring`
+        oracle.brick_stencil(NAMES[name[:-3]], info.adj_host, mid, want, 512, ids=sub, coeff=coeff)
+    else:
+        sub = np.sort(rng.choice(real, 1024, replace=False)).astype(np.uint32)
+        oracle.brick_stencil(NAMES[name], info.adj_host, hin, want, 512, ids=sub, coeff=coeff)
     got = sx.dat.cpu().numpy().reshape(-1, 512)[sub]
     assert np.abs(got - want.reshape(-1, 512)[sub]).max() <= TOL
 
