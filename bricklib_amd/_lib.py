@@ -83,6 +83,43 @@ def _load():
     L.brk_strong_neighbor.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]
     L.brk_strong_neighbor.restype = C.c_uint64
+    # ghost-zone exchange (plans, views, communicators)
+    i27 = C.c_int * 27
+    L.brk_xplan_build_decomp.argtypes = [vp, i27, C.c_int, C.c_int, C.c_uint, C.c_size_t, C.POINTER(vp)]
+    L.brk_xplan_build_tables.argtypes = [C.c_int, C.c_uint32, vp, C.c_uint32, vp, C.POINTER(vp)]
+    L.brk_xplan_free.argtypes = [vp]
+    L.brk_xplan_free.restype = None
+    L.brk_xplan_my_rank.argtypes = [vp]
+    for name in ("nstages", "ncopies", "nmsgs"):
+        f = getattr(L, "brk_xplan_" + name)
+        f.argtypes = [vp]
+        f.restype = C.c_uint32
+    from .decomp_types import XCopy, XMsg
+    L.brk_xplan_copies.argtypes = [vp]
+    L.brk_xplan_copies.restype = C.POINTER(XCopy)
+    L.brk_xplan_msgs.argtypes = [vp]
+    L.brk_xplan_msgs.restype = C.POINTER(XMsg)
+    for name in ("bytes_remote", "bytes_local"):
+        f = getattr(L, "brk_xplan_" + name)
+        f.argtypes = [vp]
+        f.restype = C.c_uint64
+    L.brk_xplan_buffer_bytes.argtypes = [vp, C.c_uint32, C.c_int, C.c_uint32]
+    L.brk_xplan_buffer_bytes.restype = C.c_uint64
+    L.brk_exchange_view_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.brk_exchange_view_free.argtypes = [vp]
+    L.brk_exchange_view_free.restype = None
+    L.brk_exchange_begin.argtypes = [vp, C.c_uint32, vp]
+    L.brk_exchange_transport.argtypes = [vp, C.c_uint32, vp, vp]
+    L.brk_exchange_end.argtypes = [vp, C.c_uint32, vp]
+    L.brk_exchange_run.argtypes = [vp, vp, vp]
+    L.brk_exchange_loopback.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, vp]
+    L.brk_exchange_view_buffer.argtypes = [vp, C.c_uint32, C.c_int, C.c_uint32]
+    L.brk_exchange_view_buffer.restype = vp
+    L.brk_exchange.argtypes = [vp, vp, C.c_size_t, vp, i27, vp]
+    L.brk_comm_unique_id.argtypes = [vp]
+    L.brk_comm_init_rank.argtypes = [C.POINTER(vp), C.c_int, vp, C.c_int]
+    L.brk_comm_destroy.argtypes = [vp]
+    L.brk_comm_rank.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return L
 
 
@@ -97,6 +134,11 @@ ABI_SYMBOLS = [
     "brk_decomp_adj", "brk_decomp_nruns", "brk_decomp_ghost", "brk_decomp_skin", "brk_decomp_nskin",
     "brk_decomp_skinlist", "brk_decomp_skin_size", "brk_allneighbors3", "brk_populate_rank_map", "brk_dims_create",
     "brk_zmort_get", "brk_zmort_set", "brk_strong_partition", "brk_strong_neighbor",
+    "brk_xplan_build_decomp", "brk_xplan_build_tables", "brk_xplan_free", "brk_xplan_my_rank", "brk_xplan_nstages",
+    "brk_xplan_ncopies", "brk_xplan_copies", "brk_xplan_nmsgs", "brk_xplan_msgs", "brk_xplan_bytes_remote",
+    "brk_xplan_bytes_local", "brk_xplan_buffer_bytes", "brk_exchange_view_create", "brk_exchange_view_free",
+    "brk_exchange_begin", "brk_exchange_transport", "brk_exchange_end", "brk_exchange_run", "brk_exchange_loopback",
+    "brk_exchange_view_buffer", "brk_exchange", "brk_comm_unique_id", "brk_comm_init_rank", "brk_comm_destroy", "brk_comm_rank",
 ]
 
 

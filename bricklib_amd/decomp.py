@@ -14,6 +14,7 @@ import torch
 
 from ._lib import Link, check, lib
 from .brick import BrickInfo, _stream
+from .decomp_types import XCopy, XMsg
 
 
 def allneighbors():
@@ -136,244 +137,273 @@ def local_links(bDecomp, storages, rank_maps, ranks):
     return links, remote
 
 
+SP_STORAGE, SP_SEND, SP_RECV = 0, 1, 2
+XCHG_MODES = {"packed": 0, "direct": 1, "shift": 2}
+XCHG_SELF_VIA_COMM = 1
+
+
+class XPlan:
+    """brk_xplan: the host-side bookkeeping of an exchange (include/brk.h).  Built by the library from a BrickDecomp and its
+    rank map (packed / direct / shift), or from explicit tables (strong scaling)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self.my_rank = lib.brk_xplan_my_rank(handle)
+        self.nstages = lib.brk_xplan_nstages(handle)
+        nc, nm = lib.brk_xplan_ncopies(handle), lib.brk_xplan_nmsgs(handle)
+        cp, mp = lib.brk_xplan_copies(handle), lib.brk_xplan_msgs(handle)
+        cf = [f for f, _ in XCopy._fields_]
+        mf = [f for f, _ in XMsg._fields_]
+        self.copies = [{f: int(getattr(cp[q], f)) for f in cf} for q in range(nc)]
+        self.msgs = [{f: int(getattr(mp[q], f)) for f in mf} for q in range(nm)]
+        self.bytes_remote = int(lib.brk_xplan_bytes_remote(handle))
+        self.bytes_local = int(lib.brk_xplan_bytes_local(handle))
+
+    @classmethod
+    def from_decomp(cls, bDecomp, rank, mode="packed", step=512, self_via_comm=False):
+        order = allneighbors()
+        ranks = (C.c_int * 27)(*[int(bDecomp.rank_map[n]) for n in order])
+        h = C.c_void_p()
+        check(lib.brk_xplan_build_decomp(bDecomp._h, ranks, int(rank), XCHG_MODES[mode],
+                                         XCHG_SELF_VIA_COMM if self_via_comm else 0, int(step), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_tables(cls, rank, copies, msgs):
+        """copies: dicts with the brk_xcopy fields; msgs: dicts with the brk_xmsg fields"""
+        ca = (XCopy * max(1, len(copies)))()
+        for q, c in enumerate(copies):
+            for f, _ in XCopy._fields_:
+                setattr(ca[q], f, int(c[f]))
+        ma = (XMsg * max(1, len(msgs)))()
+        for q, m in enumerate(msgs):
+            for f, _ in XMsg._fields_:
+                setattr(ma[q], f, int(m[f]))
+        h = C.c_void_p()
+        check(lib.brk_xplan_build_tables(int(rank), len(copies), ca, len(msgs), ma, C.byref(h)))
+        return cls(h)
+
+    def buffer_bytes(self, stage, peer, which):
+        return int(lib.brk_xplan_buffer_bytes(self._h, int(stage), int(peer), int(which)))
+
+    def peers(self, stage=None):
+        return sorted({m["peer"] for m in self.msgs if stage is None or m["stage"] == stage})
+
+    def __del__(self):
+        try:
+            lib.brk_xplan_free(self._h)
+        except Exception:
+            pass
+
+
+class Comm:
+    """An RCCL communicator created through the C ABI (brk_comm_*): no MPI, no torch in the data path.
+    Comm.bootstrap() hands rank 0's ncclUniqueId to the other ranks over an existing torch.distributed group (any backend)."""
+
+    def __init__(self, handle, rank, size):
+        self._h, self.rank, self.size = handle, rank, size
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib.brk_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, uid, rank, size):
+        h = C.c_void_p()
+        check(lib.brk_comm_init_rank(C.byref(h), int(size), C.create_string_buffer(uid, 128), int(rank)))
+        return cls(h, rank, size)
+
+    @classmethod
+    def bootstrap(cls, group=None):
+        import torch.distributed as dist
+        rank, size = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls.init_rank(box[0], rank, size)
+
+    def destroy(self):
+        if self._h:
+            check(lib.brk_comm_destroy(self._h))
+            self._h = None
+
+
+class _DevBytes:
+    """device memory owned by the library, exposed through __cuda_array_interface__ so that torch can alias it"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
 class Exchanger:
     """Ghost exchange of ONE rank's storage (the `ev.exchange()` / `bDecomp.exchange(bStorage)` call of
-    weak/main.cpp:172-183).  Self-neighbour runs become device links; the rest goes over torch.distributed:
+    weak/main.cpp:172-183; the reference's ExchangeView).  The plan comes from the C ABI (brk_xplan_build_decomp):
       mode "direct" -- one send + one recv per run, straight from/into the storage (the reference's zero-copy form,
                        include/brick-mpi.h:476-484; up to 42 messages per exchange);
-      mode "packed" -- runs bound for the same peer are packed into one buffer by brk_link_copy, ONE send + ONE recv per
-                       peer (at most 7 on a 2x2x2 grid), unpacked by brk_link_copy: fewer, larger xGMI transfers.
-    Both sides enumerate a peer's runs in run-index order (the reference's message tags), so buffers need no header."""
+      mode "packed" -- runs bound for the same peer are packed into one buffer, ONE send + ONE recv per peer (at most 7 on a
+                       2x2x2 grid), unpacked by one launch: fewer, larger xGMI transfers;
+      mode "shift"  -- three stages of <= 2 messages (MultiStageExchangeView, include/brick-mpi.h:587-681).
+    Runs whose peer is this rank are device links inside the begin launch.  For device storages every step is a call into
+    libbrk.so (brk_exchange_begin / _transport / _end on a brk_exchange_view); the transport is
+      comm=Comm(...)   ncclSend/ncclRecv in one group, issued by the library on the caller's stream (the product path),
+      comm=None        the same messages as a torch.distributed batch_isend_irecv over tensors that alias the view's buffers
+                       (backend nccl = RCCL), or -- staged=True -- a rehearsal detour through host memory and gloo.
+    CPU storages (allow_cpu_plumbing=True, gloo): the SAME plan tables interpreted with tensor copies -- test plumbing for
+    the routing logic, never a product path."""
 
-    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False, mode="direct", staged=False):
-        assert mode in ("direct", "packed")
+    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False, mode="direct", staged=False, comm=None,
+                 self_via_comm=False, plan=None):
+        assert mode in XCHG_MODES
         self.d, self.st, self.rank, self.group, self.mode = bDecomp, storage, rank, group, mode
-        self.staged = staged      # rehearsal transport, see exchange_transport()
+        self.staged, self.comm = staged, comm
         self.cpu = storage.dat.device.type == "cpu"
         if self.cpu and not allow_cpu_plumbing:
             raise RuntimeError("Exchanger on CPU tensors is test plumbing only (gloo); pass allow_cpu_plumbing=True")
-        links, remote = local_links(bDecomp, {rank: storage}, {rank: bDecomp.rank_map}, {rank})
-        self.remote = [(q, src) for _, q, src in remote]
-        step, esz, dat = storage.step, storage.dat.element_size(), storage.dat
-        self.bytes_remote = sum(bDecomp.ghost[q]["len"] for q, _ in self.remote) * step * esz
-        # per-peer buffers and copy plans: (source element offset, destination element offset, elements)
-        self.send_buf, self.recv_buf, pack, unpack = {}, {}, [], []
-        if mode == "packed":
-            peers = sorted({src for _, src in self.remote} | {bDecomp.rank_map[bDecomp.skin[q]["neighbor"]] for q, _ in self.remote})
-            for p_ in peers:
-                rq = [q for q, src in self.remote if src == p_]
-                sq = [q for q, _ in self.remote if bDecomp.rank_map[bDecomp.skin[q]["neighbor"]] == p_]
-                self.recv_buf[p_] = torch.empty(sum(bDecomp.ghost[q]["len"] for q in rq) * step, dtype=dat.dtype, device=dat.device)
-                self.send_buf[p_] = torch.empty(sum(bDecomp.skin[q]["len"] for q in sq) * step, dtype=dat.dtype, device=dat.device)
-                o = 0
-                for q in sq:
-                    n = bDecomp.skin[q]["len"] * step
-                    pack.append((dat, bDecomp.skin[q]["pos"] * step, self.send_buf[p_], o, n))
-                    o += n
-                o = 0
-                for q in rq:
-                    n = bDecomp.ghost[q]["len"] * step
-                    unpack.append((self.recv_buf[p_], o, dat, bDecomp.ghost[q]["pos"] * step, n))
-                    o += n
-        self._cpu_links, self._cpu_pack, self._cpu_unpack = [], pack, unpack
+        self.plan = plan or XPlan.from_decomp(bDecomp, rank, mode, storage.step, self_via_comm)
+        self.nstages = self.plan.nstages
+        self.bytes_remote = self.plan.bytes_remote
+        self.remote = [m for m in self.plan.msgs if not m["is_send"]]       # what arrives over the wire
+        self.messages = sum(1 for m in self.plan.msgs if m["is_send"])
+        dat = storage.dat
+        self._view = None
+        self._bufs = {}     # (stage, peer, space) -> tensor (device: aliases the view's buffer)
         if self.cpu:
-            for g, s in zip(bDecomp.ghost, bDecomp.skin):
-                if bDecomp.rank_map[g["neighbor"]] == rank:
-                    self._cpu_links.append((g["pos"] * step, s["pos"] * step, g["len"] * step))
-            self.table = self.unpack_table = None
+            self._bytes = dat.view(torch.uint8)
+            for st in range(self.nstages):
+                for p_ in self.plan.peers(st) + sorted({c[k] for c in self.plan.copies if c["stage"] == st for k in ("src_peer", "dst_peer") if c[k] >= 0}):
+                    for sp in (SP_SEND, SP_RECV):
+                        n = self.plan.buffer_bytes(st, p_, sp)
+                        if n and (st, p_, sp) not in self._bufs:
+                            self._bufs[(st, p_, sp)] = torch.empty(n, dtype=torch.uint8)
         else:
-            ptr = lambda t, o: t.data_ptr() + o * esz
-            # same-rank links and the packing copies are independent: one launch
-            self.table = LinkTable(links + [(ptr(a, ao), ptr(b, bo), n * esz) for a, ao, b, bo, n in pack], dat.device)
-            self.unpack_table = LinkTable([(ptr(a, ao), ptr(b, bo), n * esz) for a, ao, b, bo, n in unpack], dat.device)
+            h = C.c_void_p()
+            with torch.cuda.device(dat.device):
+                check(lib.brk_exchange_view_create(self.plan._h, C.c_void_p(dat.data_ptr()), C.byref(h)))
+            self._view = h
+            for st in range(self.nstages):
+                peers = set(self.plan.peers(st)) | {c[k] for c in self.plan.copies if c["stage"] == st for k in ("src_peer", "dst_peer") if c[k] >= 0}
+                for p_ in sorted(peers):
+                    for sp in (SP_SEND, SP_RECV):
+                        n = self.plan.buffer_bytes(st, p_, sp)
+                        if n:
+                            ptr = lib.brk_exchange_view_buffer(h, st, p_, sp)
+                            self._bufs[(st, p_, sp)] = torch.as_tensor(_DevBytes(ptr, n), device=dat.device)
+        # stage-0 buffers by peer (packed mode): what tests and alternative transports look at
+        self.send_buf = {p_: b for (st, p_, sp), b in self._bufs.items() if st == 0 and sp == SP_SEND}
+        self.recv_buf = {p_: b for (st, p_, sp), b in self._bufs.items() if st == 0 and sp == SP_RECV}
 
-    def _ops(self):
+    def __del__(self):
+        try:
+            if self._view:
+                self._bufs.clear()
+                lib.brk_exchange_view_free(self._view)
+        except Exception:
+            pass
+
+    # ---- CPU interpretation of the plan tables (test plumbing) ----------------------------------------------------------
+    def _space(self, stage, space, peer):
+        return self._bytes if space == SP_STORAGE else self._bufs[(stage, peer, space)]
+
+    def _cpu_phase(self, stage, phase):
+        for c in self.plan.copies:
+            if c["stage"] == stage and c["phase"] == phase and c["bytes"]:
+                src = self._space(stage, c["src_space"], c["src_peer"])[c["src_off"]:c["src_off"] + c["bytes"]]
+                self._space(stage, c["dst_space"], c["dst_peer"])[c["dst_off"]:c["dst_off"] + c["bytes"]] = src.clone()
+
+    def _msg_tensor(self, m):
+        """the tensor a message leaves from / lands in (torch transports)"""
+        if m["space"] == SP_STORAGE:
+            if self.cpu:
+                return self._bytes[m["off"]:m["off"] + m["bytes"]]
+            return self.st.dat[m["off"] // 8:(m["off"] + m["bytes"]) // 8]
+        t = self._bufs[(m["stage"], m["peer"], m["space"])]
+        n = m["bytes"] if self.cpu else m["bytes"] // 8
+        o = m["off"] if self.cpu else m["off"] // 8
+        return t[o:o + n]
+
+    def _ops(self, stage):
         import torch.distributed as dist
-        step, dat, ops = self.st.step, self.st.dat, []
-        if self.mode == "packed":
-            for p_ in sorted(self.recv_buf):
-                if self.recv_buf[p_].numel():
-                    ops.append(dist.P2POp(dist.irecv, self.recv_buf[p_], p_, self.group))
-                if self.send_buf[p_].numel():
-                    ops.append(dist.P2POp(dist.isend, self.send_buf[p_], p_, self.group))
-            return ops
-        for q, src in self.remote:   # same run order on every rank: pairwise matching is by issue order
-            g, s = self.d.ghost[q], self.d.skin[q]
-            dst = self.d.rank_map[s["neighbor"]]
-            ops.append(dist.P2POp(dist.irecv, dat[g["pos"] * step:(g["pos"] + g["len"]) * step], src, self.group))
-            ops.append(dist.P2POp(dist.isend, dat[s["pos"] * step:(s["pos"] + s["len"]) * step], dst, self.group))
-        return ops
+        return [dist.P2POp(dist.isend if m["is_send"] else dist.irecv, self._msg_tensor(m), m["peer"], self.group)
+                for m in self.plan.msgs if m["stage"] == stage]
 
-    def exchange_begin(self, stream=None):
-        """same-rank links + packing (device: one brk_link_copy launch)"""
+    # ---- the three steps of a stage ------------------------------------------------------------------------------------
+    def exchange_begin(self, stream=None, stage=0):
+        """same-rank links + packing (device: one brk_link_copy launch inside the library)"""
         if self.cpu:
-            for dpos, spos, n in self._cpu_links:
-                self.st.dat[dpos:dpos + n] = self.st.dat[spos:spos + n].clone()
-            for a, ao, b, bo, n in self._cpu_pack:
-                b[bo:bo + n] = a[ao:ao + n]
+            self._cpu_phase(stage, 0)
         else:
-            self.table.run(stream)
+            check(lib.brk_exchange_begin(self._view, stage, _stream(stream)))
 
-    def exchange_transport(self, stream=None):
-        """grouped send/recv over torch.distributed (backend nccl = RCCL over xGMI; gloo in the CPU tests)"""
-        if not self.remote:
+    def exchange_transport(self, stream=None, stage=0):
+        msgs = [m for m in self.plan.msgs if m["stage"] == stage]
+        if not msgs:
             return
         import torch.distributed as dist
+        if self.comm is not None:                      # RCCL through the C ABI
+            check(lib.brk_exchange_transport(self._view, stage, self.comm._h, _stream(stream)))
+            return
         if self.staged:
             # REHEARSAL ONLY (bench.py --backend gloo): several ranks share one GPU, where RCCL cannot run, so the packed
             # buffers take a detour through host memory and gloo.  Exercises everything around the transport call --
             # rank maps, packing order, schedules, stream hand-over -- with real processes; never the default.
-            assert self.mode == "packed"
+            assert all(m["space"] != SP_STORAGE for m in msgs), "the staged rehearsal transport needs packed buffers"
             s_ = stream or torch.cuda.current_stream()
             s_.synchronize()
-            host_s = {p_: b.cpu() for p_, b in self.send_buf.items()}
-            host_r = {p_: torch.empty(b.numel(), dtype=b.dtype) for p_, b in self.recv_buf.items()}
-            ops = []
-            for p_ in sorted(host_r):
-                if host_r[p_].numel():
-                    ops.append(dist.P2POp(dist.irecv, host_r[p_], p_, self.group))
-                if host_s[p_].numel():
-                    ops.append(dist.P2POp(dist.isend, host_s[p_], p_, self.group))
+            host, ops = [], []
+            for m in msgs:
+                dev_t = self._msg_tensor(m)
+                h_ = dev_t.cpu() if m["is_send"] else torch.empty(dev_t.numel(), dtype=dev_t.dtype)
+                host.append((m, dev_t, h_))
+                ops.append(dist.P2POp(dist.isend if m["is_send"] else dist.irecv, h_, m["peer"], self.group))
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
             with torch.cuda.stream(s_):
-                for p_, b in self.recv_buf.items():
-                    b.copy_(host_r[p_], non_blocking=False)
+                for m, dev_t, h_ in host:
+                    if not m["is_send"]:
+                        dev_t.copy_(h_, non_blocking=False)
             return
         if self.cpu or stream is None:
-            reqs = dist.batch_isend_irecv(self._ops())
-            for r in reqs:
+            for r in dist.batch_isend_irecv(self._ops(stage)):
                 r.wait()
         else:
             with torch.cuda.stream(stream):
-                reqs = dist.batch_isend_irecv(self._ops())
-                for r in reqs:
+                for r in dist.batch_isend_irecv(self._ops(stage)):
                     r.wait()
 
-    def exchange_end(self, stream=None):
-        """unpacking (packed mode only)"""
+    def exchange_end(self, stream=None, stage=0):
+        """unpacking"""
         if self.cpu:
-            for a, ao, b, bo, n in self._cpu_unpack:
-                b[bo:bo + n] = a[ao:ao + n]
-        elif self.unpack_table.n:
-            self.unpack_table.run(stream)
+            self._cpu_phase(stage, 1)
+        else:
+            check(lib.brk_exchange_end(self._view, stage, _stream(stream)))
 
     def exchange(self, stream=None):
         """Asynchronous on `stream` (default: current stream) for device storages."""
-        self.exchange_begin(stream)
-        self.exchange_transport(stream)
-        self.exchange_end(stream)
+        if self._view is not None and (self.comm is not None or not self.plan.msgs):
+            check(lib.brk_exchange_run(self._view, self.comm._h if self.comm is not None else None, _stream(stream)))
+            return
+        for st in range(self.nstages):
+            self.exchange_begin(stream, st)
+            self.exchange_transport(stream, st)
+            self.exchange_end(stream, st)
 
 
-def _pair_runs(src_ids, dst_ids):
-    """(src start, dst start, length) runs of two equally long brick id sequences that are contiguous on both sides"""
-    src_ids, dst_ids = np.asarray(src_ids, dtype=np.int64), np.asarray(dst_ids, dtype=np.int64)
-    if src_ids.size == 0:
-        return []
-    brk = np.flatnonzero((np.diff(src_ids) != 1) | (np.diff(dst_ids) != 1)) + 1
-    starts = np.concatenate([[0], brk])
-    ends = np.concatenate([brk, [src_ids.size]])
-    return [(int(src_ids[a]), int(dst_ids[a]), int(b - a)) for a, b in zip(starts, ends)]
+def exchange_loopback(exchangers, stage=0, stream=None):
+    """Transport between the views of several virtual ranks living on ONE GPU (brk_exchange_loopback): every send is copied
+    into the matching receive of the destination rank's view."""
+    arr = (C.c_void_p * len(exchangers))(*[e._view for e in exchangers])
+    check(lib.brk_exchange_loopback(arr, len(exchangers), int(stage), _stream(stream)))
 
 
-class ShiftExchanger:
+class ShiftExchanger(Exchanger):
     """Three-stage shift exchange (MultiStageExchangeView of include/brick-mpi.h:587-681): one stage per axis; in stage a
     every rank trades its two boundary layers along axis a with its -a / +a neighbours, and the layers span the ghosts
     already received along the earlier axes, so edge and corner ghosts arrive in two / three hops.  At most 2 messages
     per stage (6 per exchange, against 26 neighbours / 42 runs), at the price of three dependent stages -- the schedule
     for links where message count matters more than hop count (across nodes); on one xGMI node the packed all-neighbour
-    Exchanger uses all 7 links at once.  Layers are boxes of the logical grid, packed / unpacked / linked by brk_link_copy.
-    Results are identical to Exchanger's."""
+    Exchanger uses all 7 links at once.  Results are identical to Exchanger's.  (= Exchanger(mode="shift"); the plan is
+    built by brk_xplan_build_decomp.)"""
 
-    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False):
-        self.d, self.st, self.rank, self.group = bDecomp, storage, rank, group
-        self.cpu = storage.dat.device.type == "cpu"
-        if self.cpu and not allow_cpu_plumbing:
-            raise RuntimeError("ShiftExchanger on CPU tensors is test plumbing only (gloo); pass allow_cpu_plumbing=True")
-        g = np.asarray(bDecomp.grid).astype(np.int64)              # [k][j][i] -> brick id
-        T = [g.shape[2], g.shape[1], g.shape[0]]
-        gb = bDecomp.depth // 8
-        step, dat = storage.step, storage.dat
-        esz = dat.element_size()
-
-        def box_ids(a, lo_a, hi_a):
-            lo, hi = [0] * 3, list(T)
-            for b in range(3):
-                if b > a:                                           # not exchanged yet: the domain only
-                    lo[b], hi[b] = gb, T[b] - gb
-            lo[a], hi[a] = lo_a, hi_a
-            return np.ascontiguousarray(g[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]).reshape(-1)
-
-        self.stages = []
-        for a in range(3):
-            minus, plus = bDecomp.rank_map[1 << (32 + a)], bDecomp.rank_map[1 << (a + 1)]
-            send = [(box_ids(a, gb, 2 * gb), minus), (box_ids(a, T[a] - 2 * gb, T[a] - gb), plus)]     # low layer, high layer
-            recv = [(box_ids(a, T[a] - gb, T[a]), plus), (box_ids(a, 0, gb), minus)]                   # high ghost, low ghost
-            links, pack, unpack, sbuf, rbuf = [], [], [], {}, {}
-            for (sids, dst), (rids, src) in zip(send, recv):
-                # my low layer is what my -a neighbour receives as its high ghost: when that neighbour is me, link directly
-                if dst == rank:
-                    links += _pair_runs(sids, rids)
-            peers_s = sorted({p for _, p in send if p != rank})
-            peers_r = sorted({p for _, p in recv if p != rank})
-            for p in peers_s:
-                n = sum(ids.size for ids, q in send if q == p) * step
-                sbuf[p] = torch.empty(n, dtype=dat.dtype, device=dat.device)
-            for p in peers_r:
-                n = sum(ids.size for ids, q in recv if q == p) * step
-                rbuf[p] = torch.empty(n, dtype=dat.dtype, device=dat.device)
-            off = {p: 0 for p in peers_s}
-            for ids, p in send:
-                if p == rank:
-                    continue
-                for s0, _, ln in _pair_runs(ids, np.arange(ids.size)):
-                    pack.append((dat, s0 * step, sbuf[p], off[p], ln * step))
-                    off[p] += ln * step
-            off = {p: 0 for p in peers_r}
-            for ids, p in recv:
-                if p == rank:
-                    continue
-                for d0, _, ln in _pair_runs(ids, np.arange(ids.size)):
-                    unpack.append((rbuf[p], off[p], dat, d0 * step, ln * step))
-                    off[p] += ln * step
-            st = {"links": [(s * step, t * step, ln * step) for s, t, ln in links], "pack": pack, "unpack": unpack,
-                  "sbuf": sbuf, "rbuf": rbuf}
-            if not self.cpu:
-                ptr = lambda t, o: t.data_ptr() + o * esz
-                st["begin"] = LinkTable([(ptr(dat, s), ptr(dat, t), ln * esz) for s, t, ln in st["links"]] +
-                                        [(ptr(x, xo), ptr(y, yo), n * esz) for x, xo, y, yo, n in pack], dat.device)
-                st["end"] = LinkTable([(ptr(x, xo), ptr(y, yo), n * esz) for x, xo, y, yo, n in unpack], dat.device)
-            self.stages.append(st)
-        self.messages = sum(len(s["sbuf"]) for s in self.stages)
-        self.bytes_remote = sum(b.numel() for s in self.stages for b in s["sbuf"].values()) * esz
-
-    def exchange(self, stream=None):
-        import torch.distributed as dist
-        dat = self.st.dat
-        for st in self.stages:
-            if self.cpu:
-                for s, t, n in st["links"]:
-                    dat[t:t + n] = dat[s:s + n].clone()
-                for a, ao, b, bo, n in st["pack"]:
-                    b[bo:bo + n] = a[ao:ao + n]
-            else:
-                st["begin"].run(stream)
-            ops = []
-            for p in sorted(set(st["rbuf"]) | set(st["sbuf"])):
-                if p in st["rbuf"]:
-                    ops.append(dist.P2POp(dist.irecv, st["rbuf"][p], p, self.group))
-                if p in st["sbuf"]:
-                    ops.append(dist.P2POp(dist.isend, st["sbuf"][p], p, self.group))
-            if ops:
-                if self.cpu or stream is None:
-                    for r in dist.batch_isend_irecv(ops):
-                        r.wait()
-                else:
-                    with torch.cuda.stream(stream):
-                        for r in dist.batch_isend_irecv(ops):
-                            r.wait()
-            if self.cpu:
-                for a, ao, b, bo, n in st["unpack"]:
-                    b[bo:bo + n] = a[ao:ao + n]
-            elif st["end"].n:
-                st["end"].run(stream)
+    def __init__(self, bDecomp, storage, rank, group=None, allow_cpu_plumbing=False, **kw):
+        super().__init__(bDecomp, storage, rank, group=group, allow_cpu_plumbing=allow_cpu_plumbing, mode="shift", **kw)

@@ -591,6 +591,83 @@ def test_packed_exchange_tables_virtual_ranks(oracle, dev, nranks):
         assert (sts[r].dat.cpu().numpy() == want[r]).all(), r
 
 
+@pytest.mark.parametrize("nranks,mode", [(2, "packed"), (8, "packed"), (4, "direct"), (8, "direct"), (3, "shift"), (8, "shift")])
+def test_c_abi_exchange_views_loopback(oracle, dev, nranks, mode):
+    """The C-ABI exchange (brk_xplan_build_decomp -> brk_exchange_view_create -> begin / transport / end) for every rank
+    of a periodic grid living on this one GPU, with brk_exchange_loopback standing in for the RCCL group: storages equal
+    the oracle's run-by-run exchange bit for bit, in all three modes."""
+    from bricklib_amd.decomp import Exchanger, exchange_loopback
+    dom = (32, 16, 24)
+    cart = bl.dims_create(nranks)
+    sts, exs = [], []
+    for r in range(nranks):
+        d = bl.BrickDecomp(dom)
+        bl.populate(d, cart, rank_to_coo(r, cart))
+        st = bl.BrickStorage((torch.arange(d.nbricks * 512, dtype=torch.float64) + r * 1e9).to(dev), d.nbricks, 512)
+        sts.append(st)
+        exs.append(Exchanger(d, st, r, mode=mode))
+    assert any(e.messages for e in exs)
+    if mode == "packed":
+        assert all(e.messages <= 7 for e in exs)
+    if mode == "shift":
+        assert all(e.nstages == 3 and e.messages <= 6 for e in exs)
+    for stage in range(exs[0].nstages):
+        for e in exs:
+            e.exchange_begin(stage=stage)
+        exchange_loopback(exs, stage)
+        for e in exs:
+            e.exchange_end(stage=stage)
+    torch.cuda.synchronize()
+    od = oracle.decomp(dom)
+    want = [np.arange(od.nbricks * 512, dtype=np.float64) + r * 1e9 for r in range(nranks)]
+    oracle.exchange(od, want, [oracle.populate_rank_map(cart, rank_to_coo(r, cart)) for r in range(nranks)], 512)
+    for r in range(nranks):
+        assert (sts[r].dat.cpu().numpy() == want[r]).all(), r
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("mode", ["packed", "direct", "shift"])
+def test_c_abi_exchange_rccl_single_rank(oracle, dev, mode):
+    """The RCCL transport itself on one GPU: a 1-rank communicator created through the C ABI (brk_comm_unique_id +
+    brk_comm_init_rank), a periodic 1x1x1 decomposition whose self-neighbour runs are forced through the communicator
+    (BRK_XCHG_SELF_VIA_COMM: pack -> ncclGroupStart; ncclRecv/ncclSend to self; ncclGroupEnd -> unpack, all inside
+    libbrk.so) -- equals the oracle's exchange bit for bit.  Also the reference-shaped call brk_exchange(decomp, storage,
+    step, comm, rank_of_neighbor, stream)."""
+    from bricklib_amd.decomp import Comm, Exchanger, allneighbors
+    from bricklib_amd._lib import check, lib
+    dom = (40, 24, 32)
+    d = bl.BrickDecomp(dom)
+    bl.populate(d, [1, 1, 1], [0, 0, 0])
+    base = torch.arange(d.nbricks * 512, dtype=torch.float64)
+    od = oracle.decomp(dom)
+    want = [base.numpy().copy()]
+    oracle.exchange(od, want, [oracle.populate_rank_map([1, 1, 1], [0, 0, 0])], 512)
+    comm = Comm.init_rank(Comm.unique_id(), 0, 1)
+    try:
+        st = bl.BrickStorage(base.clone().to(dev), d.nbricks, 512)
+        ex = Exchanger(d, st, 0, mode=mode, comm=comm, self_via_comm=True)
+        assert ex.messages > 0
+        if mode != "shift":
+            assert ex.bytes_remote == sum(g["len"] for g in d.ghost) * 4096       # every run travels through the communicator
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        ex.exchange(side)                          # on a second stream, as the drivers do
+        side.synchronize()
+        assert (st.dat.cpu().numpy() == want[0]).all()
+        if mode == "packed":
+            st2 = bl.BrickStorage(base.clone().to(dev), d.nbricks, 512)
+            ranks = (C.c_int * 27)(*[d.rank_map[n] for n in allneighbors()])
+            check(lib.brk_exchange(d._h, C.c_void_p(st2.dat.data_ptr()), 512, comm._h, ranks, None))
+            torch.cuda.synchronize()
+            assert (st2.dat.cpu().numpy() == want[0]).all()
+            st3 = bl.BrickStorage(base.clone().to(dev), d.nbricks, 512)       # no communicator: every neighbour is this rank
+            check(lib.brk_exchange(d._h, C.c_void_p(st3.dat.data_ptr()), 512, None, ranks, None))
+            torch.cuda.synchronize()
+            assert (st3.dat.cpu().numpy() == want[0]).all()
+    finally:
+        comm.destroy()
+
+
 @pytest.mark.parametrize("name", ["7pt", "mpi13pt"])
 def test_large_1024_cubed_addressing(oracle, dev, name):
     """1024^3 cells = 2.2 M bricks, 9 GB per field: byte offsets beyond 2^32 in every kernel path (id list, 64-bit brick
