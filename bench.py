@@ -58,6 +58,17 @@ def parse():
                     help="weak workload, runs that leave the GPU: packed = one RCCL send+recv per peer through pack/unpack "
                          "kernels, direct = one per run straight from the storage (the reference's zero-copy form), shift = "
                          "three-stage shift exchange, <= 2 messages per stage (MultiStageExchangeView)")
+    ap.add_argument("--transport", default="abi", choices=("abi", "torch"),
+                    help="N > 1, messages that leave the GPU: abi = ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd issued inside libbrk.so "
+                         "(brk_exchange_transport) on a communicator created through the C ABI, bootstrapped over the torch.distributed "
+                         "group; torch = the same messages as torch.distributed batch_isend_irecv (backend nccl = RCCL)")
+    ap.add_argument("--self-via-comm", action="store_true",
+                    help="weak workload on ONE GPU: send the self-neighbour runs through a 1-rank RCCL communicator (ncclSend/ncclRecv "
+                         "to self inside libbrk.so) instead of device links -- exercises the whole pack -> RCCL -> unpack path, on the "
+                         "exchange stream of the chosen schedule, where only one GPU is available")
+    ap.add_argument("--watchdog-seconds", type=float, default=900.0,
+                    help="N > 1: a rank that has not finished after this long prints where it was and exits with status 3")
+    ap.add_argument("--no-scaling-base", action="store_true", help="N > 1: skip the 1-GPU run of the same workload on rank 0")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = REHEARSAL of the multi-rank control flow with several "
                          "ranks sharing one GPU, ghost bytes staged through host memory (numbers are not a measurement)")
@@ -279,12 +290,15 @@ def run_weak(args, bl, dev, rank, world):
     stA, stB = info.allocate(512, dev), info.allocate(512, dev)
     stA.dat.uniform_(0.0, 1.0)
     A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
-    if args.exchange == "shift":
-        from bricklib_amd.decomp import ShiftExchanger
-        assert args.backend == "nccl" or world == 1, "the shift exchange has no host-staged rehearsal transport"
-        ex = ShiftExchanger(d, stA, rank)
-    else:
-        ex = Exchanger(d, stA, rank, mode=args.exchange, staged=args.backend == "gloo")
+    comm = None
+    if world > 1 and args.backend == "nccl" and args.transport == "abi":
+        from bricklib_amd.decomp import Comm
+        comm = Comm.bootstrap()              # rank 0's ncclUniqueId travels over the torch.distributed group; then RCCL only
+    elif world == 1 and args.self_via_comm:
+        from bricklib_amd.decomp import Comm
+        comm = Comm.init_rank(Comm.unique_id(), 0, 1)
+    ex = Exchanger(d, stA, rank, mode=args.exchange, staged=args.backend == "gloo" and world > 1, comm=comm,
+                   self_via_comm=world == 1 and args.self_via_comm)
     if args.emulate_exchange_ms > 0:
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # calibrate torch.cuda._sleep
         torch.cuda._sleep(1000000)
@@ -316,7 +330,7 @@ def run_weak(args, bl, dev, rank, world):
 
     sum0 = global_sum()
     main = torch.cuda.current_stream()
-    comm = torch.cuda.Stream()
+    xstream = torch.cuda.Stream()            # the exchange runs here when a schedule overlaps it with sweeps
     schedule = "plain" if args.no_overlap else args.schedule
     deep_depth = args.deep_depth
     probe_ms = None
@@ -366,12 +380,12 @@ def run_weak(args, bl, dev, rank, world):
         deep_depth = S if not deep_depth else max(1, min(deep_depth, S))
 
         def step():
-            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=comm, depth=deep_depth, full=whole)
+            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=xstream, depth=deep_depth, full=whole)
     else:
         lists = SweepLists(d, dev)
 
         def step():
-            return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=comm, overlap=overlap, lists=lists, state=state)
+            return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=xstream, overlap=overlap, lists=lists, state=state)
 
     for _ in range(W):
         step()
@@ -409,12 +423,55 @@ def run_weak(args, bl, dev, rank, world):
     drift = abs(sum1 - sum0) / abs(sum0) if name in ("mpi7pt", "mpi13pt", "mpi25pt", "mpi125pt", "mpi7pt_x2") else None
     upd = 2 if name.endswith("_x2") else 1                 # a fused pass updates every cell twice
     cells = float(N) ** 3 * S * upd * world
+    # per-peer traffic of one exchange and the rate each peer link saw while the exchange ran alone (all peers at once)
+    per_peer = {}
+    for m in ex.plan.msgs:
+        if m["is_send"]:
+            per_peer[m["peer"]] = per_peer.get(m["peer"], 0) + m["bytes"]
     res = {"workload": f"weak-{name[:-3] if upd == 2 else name}-{N}", "conservation_rel_drift": drift, "updates_per_pass": upd, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,   # per pass: one read + one write per cell
            "kernel": "%s passes over brick lists of BrickDecomp(%d^3): %d passes (%d sweeps) + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S * upd, S),
-           "cart": cart, "overlap": overlap, "exchange": args.exchange, "schedule": schedule, "deep_depth": deep_depth if schedule == "deep" else None, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
-           "remote_bytes_per_rank": ex.bytes_remote}
-    return res, {}
+           "cart": cart, "overlap": overlap, "exchange": args.exchange, "transport": ("abi" if comm is not None else ("gloo-staged" if args.backend == "gloo" else "torch")) if world > 1 else ("abi: RCCL send/recv to self" if comm is not None else "device links"),
+           "schedule": schedule, "deep_depth": deep_depth if schedule == "deep" else None, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
+           "remote_bytes_per_rank": ex.bytes_remote, "messages_per_exchange": ex.messages,
+           "per_peer_send_bytes": {str(k): v for k, v in sorted(per_peer.items())},
+           "per_peer_GBps_exchange_alone": {str(k): v / (exchange_ms * 1e-3) / 1e9 for k, v in sorted(per_peer.items())} if exchange_ms > 0 else None}
+    extra = {}
+    if world > 1:
+        # which GPUs the ranks really ran on (N distinct devices under RCCL), gathered over the process group
+        props = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "device": torch.cuda.current_device(), "name": props.name,
+              "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+              "uuid": str(getattr(props, "uuid", ""))}
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        res["ranks_seen"] = seen
+        res["distinct_gpus"] = len({(x["pci"], x["uuid"]) for x in seen})
+        if not args.no_scaling_base:
+            # the like-for-like base of a scaling curve: the SAME workload (same stencil, fusion, sweeps per exchange) on one
+            # GPU with a self-periodic 1x1x1 decomposition, measured here on rank 0's GPU outside the timed region
+            base = [None]
+            if rank == 0:
+                import copy
+                a1 = copy.copy(args)
+                a1.steps, a1.warmup, a1.schedule, a1.emulate_exchange_ms = max(5, min(K, 10)), 2, "plain", 0.0
+                try:
+                    w1, _ = run_weak(a1, bl, dev, 0, 1)
+                    base[0] = w1["cells_per_step"] * w1["K"] / w1["wall"] / 1e9
+                except Exception as e:
+                    base[0] = repr(e)
+            dist.broadcast_object_list(base, src=0)
+            if isinstance(base[0], float):
+                value = cells * K / wall / 1e9
+                extra["scaling_base"] = {"value": base[0], "unit": "GStencil/s", "workload": res["workload"] + " on ONE GPU (1x1x1 periodic, device links), rank 0's GPU",
+                                         "updates_per_pass": upd}
+                extra["scaling_efficiency"] = value / (world * base[0])
+            else:
+                extra["scaling_base"] = {"error": base[0]}
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.destroy()
+    return res, extra
 
 
 def run_strong(args, bl, dev, rank, world):
@@ -432,7 +489,16 @@ def run_strong(args, bl, dev, rank, world):
     main = torch.cuda.current_stream()
     S = bl.stencil_iters(sid)
 
-    transport = staged_transport if args.backend == "gloo" else nccl_transport
+    comm = None
+    if args.backend == "gloo":
+        transport = staged_transport
+    elif world > 1 and args.transport == "abi":
+        from bricklib_amd.decomp import Comm
+        from bricklib_amd.strong import rccl_transport
+        comm = Comm.bootstrap()
+        transport = rccl_transport(comm)
+    else:
+        transport = nccl_transport
 
     def global_sum():   # see run_weak: the MPI_* stencils conserve the sum of the periodic global field
         v = sr.storages[0].dat.view(sr.nsub, sr.nb, 512)[:, 1:sr.d.sep_pos[1]].sum().reshape(1)
@@ -476,8 +542,30 @@ def run_strong(args, bl, dev, rank, world):
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * local_cells,
            "kernel": "%s sweeps over %d subdomains of %d^3 (+ghost) per rank, one launch per sweep; kernel_ms = step / %d"
                      % (name, sr.nsub, args.strong_sub, S),
-           "scaling": "strong", "updates_per_pass": upd, "conservation_rel_drift": drift, "cells_per_gpu": int(local_cells), "subdomains_per_rank": sr.nsub, "remote_bytes_per_rank": sr.bytes_remote}
+           "scaling": "strong", "updates_per_pass": upd, "conservation_rel_drift": drift, "cells_per_gpu": int(local_cells), "subdomains_per_rank": sr.nsub, "remote_bytes_per_rank": sr.bytes_remote,
+           "transport": ("abi" if comm is not None else ("gloo-staged" if args.backend == "gloo" else "torch")) if world > 1 else "device links"}
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.destroy()
     return res, {}
+
+
+def _watchdog(seconds, rank):
+    """A rank that hangs (a collective that never completes, a peer that died) must not sit there forever: after `seconds`
+    the process reports and exits with status 3.  os._exit from a timer thread: no re-exec, no retry, nothing touches the GPU."""
+    import faulthandler
+    import threading
+
+    def fire():
+        sys.stderr.write(f"bench.py: rank {rank} did not finish within {seconds:.0f} s -- giving up (exit 3)\n")
+        faulthandler.dump_traceback(file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(3)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
@@ -491,15 +579,21 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
     if args.backend == "gloo":
         local = local % torch.cuda.device_count()      # rehearsal: ranks share the GPUs that exist
+    elif world > 1 and torch.cuda.device_count() < world // max(1, int(os.environ.get("NNODES", "1"))) and local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} (local {local}) has no GPU of its own: {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    wd = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        wd = _watchdog(args.watchdog_seconds, rank)
+        tmo = datetime.timedelta(seconds=max(60.0, args.watchdog_seconds - 30.0))
         if args.backend == "gloo":
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
     workload = args.workload or ("single" if world == 1 else "weak")
     if workload == "single":
         res, extra = run_single(args, bl, dev)
@@ -530,7 +624,8 @@ def main():
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
                        **{k: res[k] for k in ("layout", "form", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
-                                             "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift") if k in res}},
+                                             "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift", "transport", "messages_per_exchange",
+                                             "per_peer_send_bytes", "per_peer_GBps_exchange_alone", "distinct_gpus", "ranks_seen") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],
                          "kernel_ms": res["kernel_ms"], "algorithmic_bytes_per_launch": res["alg_bytes_per_launch"]},
@@ -550,7 +645,19 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if wd is not None:
+        wd.cancel()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # any failure (an RCCL error, a failed check) ends the rank with a non-zero status and a traceback; torch.distributed.run
+        # then tears the other ranks down.  Nothing is retried and nothing is re-executed.
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

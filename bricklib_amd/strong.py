@@ -17,7 +17,7 @@ import torch
 
 from ._lib import check, lib
 from .brick import Brick, BrickInfo, BrickStorage, grid_to_device
-from .decomp import BrickDecomp, LinkTable
+from .decomp import SP_RECV, SP_SEND, SP_STORAGE, BrickDecomp, Exchanger, XPlan, exchange_loopback
 from .order import decomp_lists
 from .stencils import apply_stencil, stencil_iters
 
@@ -63,11 +63,11 @@ class StrongRank:
 
     # ---- exchange plan (strong/main.cu:188-395, run granularity) ----------------------------------------------
     def _plan(self):
+        """Tables for brk_xplan_build_tables: same-rank ghost runs are storage->storage links, the others are packed per
+        peer rank (canonical order on both sides: receiver Z-Morton id, run index), ONE send + ONE recv per peer."""
         d, nb, esz = self.d, self.nb, 8
-        st0 = self.storages[0]
-        base = st0.dat.data_ptr()
-        off = lambda m, pos: base + (m * nb + pos) * 512 * esz
-        local = []
+        off = lambda m, pos: (m * nb + pos) * 512 * esz          # byte offset inside storages[0]
+        copies = []
         recv, send = {}, {}       # peer -> list of (key=(receiver zmort, run), sub index, run)
         for m in range(self.nsub):
             z = self.l + m
@@ -75,36 +75,37 @@ class StrongRank:
                 # receive side: ghost run q of z comes from the subdomain in direction g.neighbor
                 zs, owner, slot = neighbor_of(g["neighbor"], z, self.subdim, self.allsubs, self.size)
                 if owner == self.rank:
-                    local.append((off(slot, s["pos"]), off(m, g["pos"]), g["len"] * 512 * esz))
+                    copies.append(dict(stage=0, phase=0, src_space=SP_STORAGE, dst_space=SP_STORAGE, src_peer=-1, dst_peer=-1,
+                                       src_off=off(slot, s["pos"]), dst_off=off(m, g["pos"]), bytes=g["len"] * 512 * esz))
                 else:
                     recv.setdefault(owner, []).append(((z, q), m, q))
                 # send side: skin run q of z goes to the subdomain in direction s.neighbor
                 zr, owner_r, _ = neighbor_of(s["neighbor"], z, self.subdim, self.allsubs, self.size)
                 if owner_r != self.rank:
                     send.setdefault(owner_r, []).append(((zr, q), m, q))
-        self.local_table = LinkTable(local, self.device)
         self.peers = sorted(set(recv) | set(send))
-        self.send_buf, self.recv_buf = {}, {}
-        pack, unpack = [], []
+        msgs = []
         for p in self.peers:
-            rl, sl = sorted(recv.get(p, [])), sorted(send.get(p, []))
-            rbytes = sum(d.ghost[q]["len"] for _, _, q in rl) * 512 * esz
-            sbytes = sum(d.skin[q]["len"] for _, _, q in sl) * 512 * esz
-            self.recv_buf[p] = torch.empty(rbytes // esz, dtype=torch.float64, device=self.device)
-            self.send_buf[p] = torch.empty(sbytes // esz, dtype=torch.float64, device=self.device)
-            o = self.send_buf[p].data_ptr()
-            for _, m, q in sl:
+            so = ro = 0
+            for _, m, q in sorted(send.get(p, [])):
                 n = d.skin[q]["len"] * 512 * esz
-                pack.append((off(m, d.skin[q]["pos"]), o, n))
-                o += n
-            o = self.recv_buf[p].data_ptr()
-            for _, m, q in rl:
+                copies.append(dict(stage=0, phase=0, src_space=SP_STORAGE, dst_space=SP_SEND, src_peer=-1, dst_peer=p,
+                                   src_off=off(m, d.skin[q]["pos"]), dst_off=so, bytes=n))
+                so += n
+            for _, m, q in sorted(recv.get(p, [])):
                 n = d.ghost[q]["len"] * 512 * esz
-                unpack.append((o, off(m, d.ghost[q]["pos"]), n))
-                o += n
-        self.pack_table = LinkTable(pack, self.device)
-        self.unpack_table = LinkTable(unpack, self.device)
-        self.bytes_remote = sum(b.numel() for b in self.send_buf.values()) * esz
+                copies.append(dict(stage=0, phase=1, src_space=SP_RECV, dst_space=SP_STORAGE, src_peer=p, dst_peer=-1,
+                                   src_off=ro, dst_off=off(m, d.ghost[q]["pos"]), bytes=n))
+                ro += n
+            if ro:
+                msgs.append(dict(stage=0, is_send=0, peer=p, space=SP_RECV, off=0, bytes=ro))
+            if so:
+                msgs.append(dict(stage=0, is_send=1, peer=p, space=SP_SEND, off=0, bytes=so))
+        plan = XPlan.from_tables(self.rank, copies, msgs)
+        # the view: buffers + device link tables inside libbrk.so; begin / transport / end are C-ABI calls
+        self.xch = Exchanger(d, self.storages[0], self.rank, mode="packed", plan=plan)
+        self.send_buf, self.recv_buf = self.xch.send_buf, self.xch.recv_buf
+        self.bytes_remote = plan.bytes_remote
 
     # ---- data movement ----------------------------------------------------------------------------------------
     def origin(self, m):
@@ -118,13 +119,12 @@ class StrongRank:
         return Brick(self.d.getBrickInfo(self.device), view, 0)
 
     def exchange_begin(self, stream=None):
-        """same-rank links (strong/main.cu:440-443) and pack (:479-482)"""
-        self.local_table.run(stream)
-        self.pack_table.run(stream)
+        """same-rank links (strong/main.cu:440-443) and pack (:479-482): one launch"""
+        self.xch.exchange_begin(stream)
 
     def exchange_end(self, stream=None):
         """unpack (strong/main.cu:459-462)"""
-        self.unpack_table.run(stream)
+        self.xch.exchange_end(stream)
 
     def exchange(self, transport, stream=None):
         """transport(self, stream) moves send_buf[p] of this rank into recv_buf[self.rank] of peer p."""
@@ -145,43 +145,33 @@ class StrongRank:
         return S
 
 
+def rccl_transport(comm):
+    """the product transport: ncclGroupStart; ncclRecv/ncclSend per peer; ncclGroupEnd inside libbrk.so (brk_exchange_transport)
+    on a communicator created through the C ABI (bricklib_amd.decomp.Comm)"""
+    def go(sr, stream=None):
+        sr.xch.comm = comm
+        sr.xch.exchange_transport(stream)
+    return go
+
+
 def nccl_transport(sr, stream=None):
-    """one send + one recv per peer rank over torch.distributed (RCCL)"""
-    import torch.distributed as dist
-    ops = []
-    for p in sr.peers:
-        if sr.recv_buf[p].numel():
-            ops.append(dist.P2POp(dist.irecv, sr.recv_buf[p], p))
-        if sr.send_buf[p].numel():
-            ops.append(dist.P2POp(dist.isend, sr.send_buf[p], p))
-    ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
-    with ctx:
-        for r in dist.batch_isend_irecv(ops):
-            r.wait()
+    """the same messages over torch.distributed (backend nccl = RCCL): batch_isend_irecv on tensors aliasing the view's buffers"""
+    sr.xch.comm, sr.xch.staged = None, False
+    sr.xch.exchange_transport(stream)
 
 
 def loopback_transport(all_ranks):
-    """Transport for several virtual ranks living on one GPU: peer p's recv buffer for r is r's send buffer for p."""
+    """Transport for several virtual ranks living on one GPU (brk_exchange_loopback): every send is copied into the matching
+    receive of the destination rank's view.  Runs once all ranks have packed: call with the last rank."""
+    last = [r for r in all_ranks if r.peers][-1:]
+
     def go(sr, stream=None):
-        for p in sr.peers:
-            all_ranks[p].recv_buf[sr.rank].copy_(sr.send_buf[p])
+        if last and sr is last[0]:
+            exchange_loopback([r.xch for r in all_ranks], 0, stream)
     return go
 
 
 def staged_transport(sr, stream=None):
     """REHEARSAL ONLY (bench.py --backend gloo): ranks share one GPU, buffers detour through host memory and gloo."""
-    import torch.distributed as dist
-    (stream or torch.cuda.current_stream()).synchronize()
-    host_s = {p: sr.send_buf[p].cpu() for p in sr.peers}
-    host_r = {p: torch.empty(sr.recv_buf[p].numel(), dtype=torch.float64) for p in sr.peers}
-    ops = []
-    for p in sr.peers:
-        if host_r[p].numel():
-            ops.append(dist.P2POp(dist.irecv, host_r[p], p))
-        if host_s[p].numel():
-            ops.append(dist.P2POp(dist.isend, host_s[p], p))
-    for r in dist.batch_isend_irecv(ops):
-        r.wait()
-    with torch.cuda.stream(stream or torch.cuda.current_stream()):
-        for p in sr.peers:
-            sr.recv_buf[p].copy_(host_r[p])
+    sr.xch.comm, sr.xch.staged = None, True
+    sr.xch.exchange_transport(stream)

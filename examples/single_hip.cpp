@@ -35,15 +35,10 @@
 
 typedef Brick<Dim<BDIM>, Dim<VFOLD>> Brick3D;
 
-// kernel argument form of a brick field: the reference passes Brick objects by value (3axis.hip.cpp:32-35); a Brick
-// holds a shared_ptr, so this example passes the three things device code needs
-struct BrickDev {
-  BrickInfo<3> *bInfo;
-  bElem *dat;
-  size_t step;
-};
+// Brick objects travel to the kernels BY VALUE, exactly as in the reference (stencils/3axis.hip.cpp:32-41,165-171): a Brick
+// built from the device BrickInfo (movBrickInfoDeep) and the device BrickStorage (movBrickStorage).
 
-__global__ void d3pt7_brick_trans(unsigned (*grid)[STRIDEB][STRIDEB], BrickDev bIn, BrickDev bOut, bElem *coeff) {
+__global__ void d3pt7_brick_trans(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Brick3D bOut, bElem *coeff) {
   long tk = GB + hipBlockIdx_z;
   long tj = GB + hipBlockIdx_y;
   long ti = GB + hipBlockIdx_x;
@@ -52,7 +47,7 @@ __global__ void d3pt7_brick_trans(unsigned (*grid)[STRIDEB][STRIDEB], BrickDev b
 }
 
 // d3cond_brick_trans of the reference (stencils/3axis.hip.cpp:214-223): same shape, "cond.py"
-__global__ void d3cond_brick_trans(unsigned (*grid)[STRIDEB][STRIDEB], BrickDev bIn, BrickDev bOut, bElem *coeff) {
+__global__ void d3cond_brick_trans(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Brick3D bOut, bElem *coeff) {
   long tk = GB + hipBlockIdx_z;
   long tj = GB + hipBlockIdx_y;
   long ti = GB + hipBlockIdx_x;
@@ -62,7 +57,7 @@ __global__ void d3cond_brick_trans(unsigned (*grid)[STRIDEB][STRIDEB], BrickDev 
 
 // A stencil the library has no hand-written kernel for: examples/lap19.py (19 points, written for this example).
 // tools/brkscatter reads the script as data and emits the generic tap path.
-__global__ void lap19_brick(unsigned (*grid)[STRIDEB][STRIDEB], BrickDev bIn, BrickDev bOut, bElem *coeff) {
+__global__ void lap19_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Brick3D bOut, bElem *coeff) {
   long tk = GB + hipBlockIdx_z;
   long tj = GB + hipBlockIdx_y;
   long ti = GB + hipBlockIdx_x;
@@ -124,8 +119,7 @@ int main() {
 
   // (1) reference-shaped kernel, brick(...) line rewritten by tools/brkscatter
   {
-    BrickDev dIn{binfo_dev, bstorage_dev.dat.get(), bstorage_dev.step};
-    BrickDev dOut{binfo_dev, bstorage_dev.dat.get() + bsize, bstorage_dev.step};
+    Brick3D dIn(binfo_dev, bstorage_dev, 0), dOut(binfo_dev, bstorage_dev, bsize);
     dim3 block(NB, NB, NB), thread(64);
     hipLaunchKernelGGL(d3pt7_brick_trans, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
     gpuCheck(hipDeviceSynchronize());
@@ -164,8 +158,7 @@ int main() {
                           coeff[0] * max(arr_in[k][j][i], 0.0);
           arr_out[k][j][i] = partial > 0 ? partial : -partial;
         }
-    BrickDev dIn{binfo_dev, bstorage_dev.dat.get(), bstorage_dev.step};
-    BrickDev dOut{binfo_dev, bstorage_dev.dat.get() + bsize, bstorage_dev.step};
+    Brick3D dIn(binfo_dev, bstorage_dev, 0), dOut(binfo_dev, bstorage_dev, bsize);
     dim3 block(NB, NB, NB), thread(64);
     hipLaunchKernelGGL(d3cond_brick_trans, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
     gpuCheck(hipDeviceSynchronize());
@@ -185,8 +178,7 @@ int main() {
           }
           arr_out[k][j][i] = acc;
         }
-    BrickDev dIn{binfo_dev, bstorage_dev.dat.get(), bstorage_dev.step};
-    BrickDev dOut{binfo_dev, bstorage_dev.dat.get() + bsize, bstorage_dev.step};
+    Brick3D dIn(binfo_dev, bstorage_dev, 0), dOut(binfo_dev, bstorage_dev, bsize);
     dim3 block(NB, NB, NB), thread(64);
     hipLaunchKernelGGL(lap19_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
     gpuCheck(hipDeviceSynchronize());

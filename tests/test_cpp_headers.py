@@ -95,6 +95,42 @@ def test_unrewritten_brick_macro_fails_to_compile(tmp_path):
     assert r.returncode != 0 and b"brkscatter" in r.stderr
 
 
+REF = "/root/reference"
+REF_EXE = os.path.join(ROOT, "examples", "_ref", "single_hip_ref")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "stencils")), reason="needs the reference tree (build container only)")
+def test_reference_single_hip_builds_unchanged():
+    """The reference's OWN single/hip driver -- single/hip.cpp + stencils/3axis.hip.cpp, read from where they lie, zero source
+    edits -- goes through tools/brkscatter (two brick(...) lines and the tile(...) line of 3axis.hip.cpp:75) and hipcc against
+    this repository's headers and libbrk.so (examples/Makefile target `ref`).  The by-value Brick kernel arguments of
+    3axis.hip.cpp:16-41 are the real signature.  Only the binary is kept (examples/_ref/, git-ignored)."""
+    if os.path.exists(REF_EXE):
+        os.remove(REF_EXE)
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "examples"), "ref"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert "2 brick(...) and 1 tile(...) call(s) rewritten" in out
+    assert os.path.exists(REF_EXE)
+    # nothing of the rewritten translation unit stays in the tree
+    assert not [f for f in os.listdir(os.path.join(ROOT, "examples", "_ref")) if f != "single_hip_ref"]
+
+
+@pytest.mark.gpu
+def test_reference_single_hip_runs():
+    """the binary built by test_reference_single_hip_builds_unchanged (prebuilt in the container, it travels like oracle/_ref):
+    d3pt7hip and d3condhip of the reference run every variant (Arr / Arr warp / Arr scatter = the tile(...) line / Bri =
+    the accessor kernel / Trans = the rewritten brick(...) line) at N = 256 and validate with compareBrick."""
+    if not os.path.exists(REF_EXE):
+        pytest.skip("examples/_ref/single_hip_ref was not prebuilt (needs the reference tree at build time)")
+    r = subprocess.run([REF_EXE], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-2000:]
+    assert "result mismatch" not in out
+    for tag in ("d3pt7", "Arr scatter:", "Bri:", "Trans:", "d3cond"):
+        assert tag in out, out
+
+
 @pytest.mark.gpu
 def test_example_driver_runs():
     exe = os.path.join(ROOT, "examples", "single_hip")

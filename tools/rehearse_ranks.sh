@@ -4,12 +4,12 @@
 set -o pipefail
 mkdir -p gpurun_out/rehearse
 port=29520
-for cfg in "2 plain" "2 surface" "2 deep" "2 auto" "4 deep" "4 surface" "4 auto"; do   # at most 4 ranks: a one-GPU test box allows 6 processes on the card, launcher included
+for cfg in "2 plain packed" "2 surface packed" "2 deep packed" "2 auto packed" "4 deep packed" "4 surface packed" "4 auto packed" "2 plain shift" "4 deep shift" "3 plain shift"; do   # at most 4 ranks: a one-GPU test box allows 6 processes on the card, launcher included
   set -- $cfg
   port=$((port + 1))
-  out=gpurun_out/rehearse/n$1_$2
+  out=gpurun_out/rehearse/n$1_$2_$3
   timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node $1 --master-addr 127.0.0.1 --master-port $port \
-    bench.py --gpus $1 --backend gloo --cells 256 --steps 3 --warmup 1 --no-cpu-baseline --schedule $2 > $out.out 2> $out.err
+    bench.py --gpus $1 --backend gloo --cells 256 --steps 3 --warmup 1 --no-cpu-baseline --schedule $2 --exchange $3 > $out.out 2> $out.err
   rc=$?
   if [ $rc -ne 0 ]; then echo "N=$1 $2 FAILED rc=$rc"; tail -15 $out.err; exit 1; fi
   python3 - $out.out "$cfg" <<'PY'
@@ -18,8 +18,9 @@ line = [l for l in open(sys.argv[1]) if l.startswith("{")][-1]
 d = json.loads(line)
 c = d["config"]
 print(sys.argv[2], "cart", c["cart"], "schedule", c["schedule"], "remote MB", round(c["remote_bytes_per_rank"] / 1e6, 1),
-      "conservation drift", c["conservation_rel_drift"])
+      "msgs", c["messages_per_exchange"], "conservation drift", c["conservation_rel_drift"], "scaling_efficiency (rehearsal, not a measurement)", round(d["scaling_efficiency"], 3))
 assert c["conservation_rel_drift"] < 1e-12
+assert len(c["ranks_seen"]) == d["n_gpus"] and "scaling_base" in d
 PY
 done
 # strong workload: global 256^3 in 64^3 subdomains over 2 and 3 ranks
