@@ -324,6 +324,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
         const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
         if (PIPE == 1) cube125_accumulate<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
         else if (PIPE == 2) cube125_accumulate_static<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
+        else if (PIPE == 3) cube125_accumulate_rows<TL::T * 8, 8, 3>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
+        else if (PIPE == 4) cube125_accumulate_rows<TL::T * 8, 8, 5>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
         else cube125_accumulate_simple<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
       } else {
         double acc[8];
@@ -358,9 +360,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 
 } // namespace
 
-// variants: 27-pt 0/6 = NW 4 (default), 5 = NW 8; 125-pt 0/5 = NW 4, 3 waves/SIMD, fully unrolled plane loop with static
-// accumulators (default), 9 = the same with the rolled loop over a ring, 6 = NW 4 and 7 = NW 8 with the software-pipelined
-// rolled loop (2 waves/SIMD)
+// variants: 27-pt 0/6 = NW 4 (default), 5 = NW 8; 125-pt 0/10 = NW 4, 3 waves/SIMD, row-pipelined plane loop (default), 11 = the
+// same with 5 rows in flight (spills), 5 = fully unrolled plane loop with static accumulators and one read burst per plane,
+// 9 = the same with the rolled loop over a ring, 6 = NW 4 and 7 = NW 8 with the software-pipelined rolled loop (2 waves/SIMD)
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8, wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
@@ -377,10 +379,14 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 2>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 7) {
     hipLaunchKernelGGL((k_cube_dense<kCube125, 8, 2>), dim3(wgs8), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (variant == 11) { // row-pipelined plane loop with 5 rows in flight (spills)
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 4>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 9) {
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 0>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
-  } else {
+  } else if (variant == 5) { // fully unrolled plane loop, reads of a plane in one burst (the round-1 default)
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 2>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else { // default (0, 10): row-pipelined plane loop, 3 rows of LDS reads in flight
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 3>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;

@@ -436,6 +436,73 @@ __device__ __forceinline__ void cube125_accumulate_static(const double *rowp, co
   }
 }
 
+// Software-pipelined form of the same accumulation.  What the counters said about cube125_accumulate_static (profiles/
+// r01_j_pmc_125pt_512.txt): the LDS pipe is busy 56 % and the fp64 pipe 53 % of the kernel, one after the other -- each plane
+// is 25 ds_read_b64 in a burst, a full wait, then ~61 VALU operations, and three waves per SIMD do not interleave that by
+// themselves.  Here ONE wave overlaps the two pipes: the plane loop is cut into 60 row steps (plane kk, row dj); step r
+//   (1) issues the 5 reads of row r + D                     (D rows = 5 D values in flight, counted lgkmcnt waits),
+//   (2) multiplies one output's share of the PREVIOUS plane (its folded values are complete): 6 FMAs,
+//   (3) folds row r into the current plane's values         (2 + 3 adds),
+// so a read has ~D x 56 cycles of fp64 work between issue and use.  Further, the class weights are symmetric in (|di|,|dj|)
+// too (stencils/mpi125pt.py:12-33: the class is the SORTED triple), so the folded plane u[a][b] is folded once more,
+// u[a][b] + u[b][a], and an output takes 6 FMAs per plane instead of 9: 19 adds per plane + 6 FMAs per (plane, output)
+// = 468 fp64 operations per lane instead of 552.  Summation order differs from the other forms in the last bits only.
+template <int PS, int RS, int D = 3>
+__device__ __forceinline__ void cube125_accumulate_rows(const double *rowp, const int (&co)[5], const Coeffs &cf,
+                                                        double *dst, int lane) {
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+  const double *colp[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) colp[d] = rowp + co[d];
+  double v[D + 1][5]; // rows in flight
+  double un[3][3];    // plane being folded: un[a][b], a = |di|, b = |dj|
+  double w[6];        // previous plane, folded in (a, b) too: (0,0) (1,1) (2,2) (0,1) (0,2) (1,2)
+  constexpr int wa[6] = {0, 1, 2, 0, 0, 1}, wb[6] = {0, 1, 2, 1, 2, 2};
+  auto load_row = [&](int r) __attribute__((always_inline)) {
+    const int kk = r / 5, dj = r % 5 - 2;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) v[r % (D + 1)][d] = colp[d][kk * PS + dj * RS];
+  };
+  // output k = pl - 4 + m receives plane pl through |dk| = |2 - m|
+  auto fma_chunk = [&](int pl, int m) __attribute__((always_inline)) {
+    const int k = pl - 4 + m;
+    if (k >= 0 && k < 8) {
+      const int c = m < 2 ? 2 - m : m - 2;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) acc[k] += cf.c[cls125(c, wb[q], wa[q])] * w[q];
+    }
+    if (m == 0 && pl >= 4) store_result(&dst[(pl - 4) * 64 + lane], acc[pl - 4]); // output pl-4 has received its last plane
+  };
+#pragma unroll
+  for (int r = 0; r < D; ++r) load_row(r);
+#pragma unroll
+  for (int r = 0; r < 60; ++r) {
+    const int pl = r / 5, q = r % 5;
+    if (r + D < 60) load_row(r + D);
+    __builtin_amdgcn_sched_barrier(0);
+    if (pl > 0) fma_chunk(pl - 1, 4 - q); // m = 4 (the newest output) first, m = 0 (retired and stored) last
+    {
+      const double(&x)[5] = v[r % (D + 1)];
+      const double s0 = x[2], s1 = x[1] + x[3], s2 = x[0] + x[4];
+      const int bcls = q < 2 ? 2 - q : q - 2;
+      if (q <= 2) {
+        un[0][bcls] = s0, un[1][bcls] = s1, un[2][bcls] = s2;
+      } else {
+        un[0][bcls] += s0, un[1][bcls] += s1, un[2][bcls] += s2;
+      }
+    }
+    if (q == 4) { // plane complete: fold (a, b) <-> (b, a) and hand it to the multiplier
+      w[0] = un[0][0], w[1] = un[1][1], w[2] = un[2][2];
+      w[3] = un[0][1] + un[1][0], w[4] = un[0][2] + un[2][0], w[5] = un[1][2] + un[2][1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int m = 4; m >= 0; --m) fma_chunk(11, m);
+}
+
 // Load brick `b` (wave-uniform) with its full halo of radius R into `tile` (this wave's private LDS slice of
 // CubeTile<R>::ELEMS doubles): own brick and the 6 faces by structured coalesced loads, edge/corner cells through the
 // descriptor table.
