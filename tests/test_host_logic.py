@@ -109,6 +109,59 @@ def test_zmort_and_strong_partition(oracle, golden):
                 assert (int(nz), o.value, s.value) == oracle.strong_getrank(n, zid, subdim, size)
 
 
+def test_populate_and_dims_match_reference_under_mpi(oracle, golden):
+    """tests/golden/populate_ranks.npz + dims_create.npz = the REFERENCE's populate() (include/brick-mpi.h:730-753) and
+    MPI_Dims_create as weak/args.cpp:105 calls it, run under mpirun -np {1,2,3,4,6,8,12,16} (oracle/gen_golden_mpi.py):
+    the C ABI (brk_populate_rank_map, brk_dims_create) and the oracle restatement reproduce every rank's map."""
+    z, dm = golden("populate_ranks"), golden("dims_create")["n_dims"]
+    def smooth7(n):                       # brk_dims_create covers sizes whose prime factors are 2, 3, 5, 7 (include/brk.h)
+        for p in (2, 3, 5, 7):
+            while n % p == 0:
+                n //= p
+        return n == 1
+    for n, d0, d1, d2 in dm:
+        if smooth7(int(n)):
+            assert bl.dims_create(int(n)) == [int(d0), int(d1), int(d2)], n
+    d = bl.BrickDecomp((16, 16, 16))
+    order = bl.allneighbors()
+    for n in z["sizes"]:
+        cart = [int(x) for x in z[f"dims_{n}"]]
+        assert bl.dims_create(int(n)) == cart
+        for rank in range(int(n)):
+            coo = [int(x) for x in z[f"coo_{n}"][rank]]
+            assert bl.decomp.rank_to_coo(rank, cart) == coo                      # MPI_Cart_coords is row-major
+            rm = bl.populate(d, cart, coo)
+            want = [int(x) for x in z[f"map_{n}"][rank]]
+            assert [rm[s] for s in order] == want, (n, rank)
+            assert [int(x) for x in oracle.populate_rank_map(cart, coo)] == want
+
+
+def test_strong_ownership_matches_reference_under_mpi(oracle, golden):
+    """tests/golden/strong_getrank.npz = getrank() and the ownership ranges of the reference's strong/args.cpp:36-56,104-113,
+    compiled as they are and run under mpirun (9 cases, 1..8 ranks, 8..512 subdomains): brk_strong_partition /
+    brk_strong_neighbor and the oracle restatement agree for every (subdomain, neighbour)."""
+    z = golden("strong_getrank")
+    for n, d, s in z["cases"]:
+        n, d, s = int(n), int(d), int(s)
+        subdim = d // s
+        allsubs = subdim ** 3
+        rng = z[f"range_{n}_{d}_{s}"]
+        for rank in range(n):
+            lr = (C.c_uint64 * 2)()
+            lib.brk_strong_partition(allsubs, n, rank, lr)
+            assert [int(lr[0]), int(lr[1])] == [int(rng[rank][0]), int(rng[rank][1])]
+            assert oracle.strong_partition(allsubs, n, rank)[:2] == [int(rng[rank][0]), int(rng[rank][1])]
+        g = z[f"getrank_{n}_{d}_{s}"]
+        assert g.shape[0] == allsubs * 27
+        for owner, zid, nset, znew, dst, sub in g:
+            o, sl = C.c_int(), C.c_int()
+            nz = lib.brk_strong_neighbor(int(nset), int(zid), subdim, allsubs, n, C.byref(o), C.byref(sl))
+            assert (int(nz), o.value, sl.value) == (int(znew), int(dst), int(sub)), (n, d, s, int(zid), int(nset))
+            assert int(rng[int(owner)][0]) <= int(zid) < int(rng[int(owner)][1])
+        for owner, zid, nset, znew, dst, sub in g[::7]:
+            assert oracle.strong_getrank(int(nset), int(zid), subdim, n) == (int(znew), int(dst), int(sub))
+
+
 def test_exchange_plan_covers_ghost_once():
     d = bl.BrickDecomp((32, 32, 32))
     covered = np.zeros(d.nbricks, dtype=np.int32)
