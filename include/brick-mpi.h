@@ -1,14 +1,18 @@
 // brick-mpi.h -- BrickDecomp and friends (reference include/brick-mpi.h:178-753, src/brick-mpi.cpp:9-52) on top of the
 // layout builder of libbrk.so (brk_decomp_*): region-ordered brick numbering, ghost / skin run tables, adjacency, the
-// neighbour -> rank map, and -- when an MPI implementation is present at compile time -- the run-by-run exchange over
-// MPI (pass device pointers with a GPU-aware MPI, as weak/main.cu does).  The RCCL transports of this library live in
-// bricklib_amd/decomp.py; INTEGRATION.md shows the link tables a C++ driver builds for them.
+// neighbour -> rank map, and the ghost-zone exchange:
+//   * ExchangeView / MultiStageExchangeView (reference :82-165, created by exchangeView / multiStageExchangeView :525-681)
+//     and BrickDecomp::exchange(bStorage) (:466-495) on DEVICE storages: GPU-resident pack -> ncclSend/ncclRecv in one
+//     group -> unpack, all inside libbrk.so (brk_exchange_*), on the communicator in BrickDecomp::rccl_comm;
+//   * when an MPI implementation is present at compile time and no RCCL communicator has been set: the reference's
+//     run-by-run exchange over MPI (host storages, or device pointers with a GPU-aware MPI as weak/main.cu does).
 // Only the configuration the reference's drivers use is provided: 3 dimensions, 8x8x8 bricks, the skin3d_good section order.
 #pragma once
 
 #include <ostream>
 #include <stdexcept>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "bitset.h"
@@ -19,6 +23,35 @@
 #include <mpi.h>
 #define BRK_HAVE_MPI 1
 #endif
+
+// The exchange of one storage as an object (reference ExchangeView :82-123 and MultiStageExchangeView :131-165: built once,
+// exchange() every time step).  Here it owns an exchange plan and a view of libbrk.so: per-peer buffers and link tables on the
+// GPU; exchange() enqueues begin (links + pack) -> ncclSend/ncclRecv group -> end (unpack) for every stage on `stream`.
+struct ExchangeView {
+  brk_xplan *plan = nullptr;
+  brk_exchange_view *view = nullptr;
+  void *rccl_comm = nullptr;  // ncclComm_t; may be null when every neighbour is this rank
+  void *stream = nullptr;     // hipStream_t the exchange is enqueued on (null stream by default, like the reference's drivers)
+  std::vector<size_t> seclen; // bytes of every message this rank sends (reference member of the same name)
+
+  ExchangeView() = default;
+  ExchangeView(const ExchangeView &) = delete;
+  ExchangeView &operator=(const ExchangeView &) = delete;
+  ExchangeView(ExchangeView &&o) noexcept { *this = std::move(o); }
+  ExchangeView &operator=(ExchangeView &&o) noexcept {
+    std::swap(plan, o.plan), std::swap(view, o.view), std::swap(rccl_comm, o.rccl_comm), std::swap(stream, o.stream);
+    seclen.swap(o.seclen);
+    return *this;
+  }
+  ~ExchangeView() {
+    brk_exchange_view_free(view);
+    brk_xplan_free(plan);
+  }
+  void exchange() {
+    if (brk_exchange_run(view, rccl_comm, stream) != BRK_OK) throw std::runtime_error(brk_last_error());
+  }
+};
+typedef ExchangeView MultiStageExchangeView; // the three-stage form is the same object over a BRK_XCHG_SHIFT plan
 
 // timing accumulators the reference's drivers print (src/brick-mpi.cpp:7)
 inline double packtime = 0, calltime = 0, waittime = 0, movetime = 0, calctime = 0;
@@ -50,6 +83,7 @@ public:
   MPI_Comm comm = MPI_COMM_NULL;
 #endif
   std::unordered_map<uint64_t, int> rank_map;             // BitSet::set -> rank, filled by populate()
+  void *rccl_comm = nullptr;                              // ncclComm_t for the device exchange (brkCommFromMPI / brk_comm_init_rank)
 
   BrickDecomp(const std::vector<unsigned> &dims_cells, unsigned depth_cells, unsigned numfield = 1) : numfield_(numfield) {
     constexpr unsigned bd[3] = {BDims...};
@@ -113,9 +147,54 @@ public:
   unsigned nbricks() const { return brk_decomp_nbricks(h_); }
   const brk_decomp *handle() const { return h_; }
 
+  // neighbour ranks in the order the C ABI wants them (brk_allneighbors3)
+  void ranks27(int out[27]) const {
+    uint64_t nb[27];
+    brk_allneighbors3(nb);
+    for (int q = 0; q < 27; ++q) {
+      auto it = rank_map.find(nb[q]);
+      if (it == rank_map.end()) throw std::runtime_error("BrickDecomp: populate() has not filled rank_map");
+      out[q] = it->second;
+    }
+  }
+
+  // exchangeView(bStorage) of the reference (:525-585): the exchange of one DEVICE storage as an object.  mode: BRK_XCHG_PACKED
+  // (one message per peer, default), BRK_XCHG_DIRECT (one per run, the reference's message pattern), BRK_XCHG_SHIFT.
+  // flags: BRK_XCHG_SELF_VIA_COMM sends runs whose peer is this rank through the communicator too (single-GPU tests of the transport).
+  ExchangeView exchangeView(const BrickStorage &bStorage_dev, int mode = BRK_XCHG_PACKED, unsigned flags = 0) const {
+    int ranks[27];
+    ranks27(ranks);
+    ExchangeView ev;
+    ev.rccl_comm = rccl_comm;
+    if (brk_xplan_build_decomp(h_, ranks, ranks[13], mode, flags, bStorage_dev.step, &ev.plan) != BRK_OK ||
+        brk_exchange_view_create(ev.plan, bStorage_dev.dat.get(), &ev.view) != BRK_OK)
+      throw std::runtime_error(brk_last_error());
+    const brk_xmsg *m = brk_xplan_msgs(ev.plan);
+    for (uint32_t q = 0; q < brk_xplan_nmsgs(ev.plan); ++q)
+      if (m[q].is_send) ev.seclen.push_back((size_t)m[q].bytes);
+    return ev;
+  }
+  // multiStageExchangeView(bStorage) of the reference (:587-681): three stages of <= 2 messages
+  MultiStageExchangeView multiStageExchangeView(const BrickStorage &bStorage_dev) const { return exchangeView(bStorage_dev, BRK_XCHG_SHIFT); }
+
+  // bDecomp.exchange(bStorage) on a DEVICE storage through libbrk.so: pack -> RCCL -> unpack (plan and view are cached in the
+  // library per storage).  Without a communicator this is legal only when every neighbour is this rank (1-rank periodic runs).
+  void exchange_device(BrickStorage &bStorage_dev, void *stream = nullptr) {
+    int ranks[27];
+    ranks27(ranks);
+    if (brk_exchange(h_, bStorage_dev.dat.get(), bStorage_dev.step, rccl_comm, ranks, stream) != BRK_OK)
+      throw std::runtime_error(brk_last_error());
+  }
+#ifndef BRK_HAVE_MPI
+  // no MPI at compile time: exchange() IS the device exchange (reference signature, include/brick-mpi.h:466)
+  void exchange(BrickStorage &bStorage) { exchange_device(bStorage); }
+#endif
+
 #ifdef BRK_HAVE_MPI
-  // ghost run i <- skin run i of the rank behind ghost[i].neighbor, tag i (reference include/brick-mpi.h:466-495)
+  // ghost run i <- skin run i of the rank behind ghost[i].neighbor, tag i (reference include/brick-mpi.h:466-495);
+  // with an RCCL communicator set, the storage is taken to live on the GPU and goes through libbrk.so instead
   void exchange(BrickStorage &bStorage) {
+    if (rccl_comm) return exchange_device(bStorage);
     std::vector<MPI_Request> req(ghost.size() * 2);
     bElem *dat = bStorage.dat.get();
     const size_t bytes_per_brick = bStorage.step * sizeof(bElem);
@@ -187,6 +266,20 @@ void populate_cart(BrickDecomp<dim, BDims...> &bDecomp, const int cart_dims[3], 
   for (int q = 0; q < 27; ++q) bDecomp.rank_map[nb[q]] = out[q];
 }
 #ifdef BRK_HAVE_MPI
+// An RCCL communicator over the ranks of an MPI communicator: rank 0's ncclUniqueId travels by MPI_Bcast, every rank joins
+// (one rank per GPU; call after hipSetDevice).  The result goes into BrickDecomp::rccl_comm.
+inline void *brkCommFromMPI(MPI_Comm comm) {
+  int rank = 0, size = 1;
+  MPI_Comm_rank(comm, &rank);
+  MPI_Comm_size(comm, &size);
+  char id[128];
+  if (rank == 0 && brk_comm_unique_id(id) != BRK_OK) throw std::runtime_error(brk_last_error());
+  MPI_Bcast(id, 128, MPI_CHAR, 0, comm);
+  void *c = nullptr;
+  if (brk_comm_init_rank(&c, size, id, rank) != BRK_OK) throw std::runtime_error(brk_last_error());
+  return c;
+}
+
 template <unsigned dim, unsigned... BDims>
 void populate(MPI_Comm &comm, BrickDecomp<dim, BDims...> &bDecomp, BitSet neighbor, int d, int *coo) {
   if (neighbor.set != 0 || d != 1) throw std::runtime_error("populate: call with (comm, bDecomp, 0, 1, coo)");

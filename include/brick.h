@@ -8,6 +8,7 @@
 #include <stdlib.h>
 
 #include <memory>
+#include <stdexcept>
 #include <type_traits>
 
 #include "vecscatter.h"
@@ -45,6 +46,16 @@ struct BrickStorage {
     s.dat = std::shared_ptr<bElem>(static_cast<bElem *>(aligned_alloc(ALIGN, bytes)), [](bElem *p) { free(p); });
     return s;
   }
+
+  // The reference's memfd/mmap allocators (include/brick.h:78-81, src/memfd.cpp) build ALIASED host mappings so that one
+  // MPI message covers a neighbour's ghost regions.  That is a host virtual-memory device; on the GPU the same effect comes
+  // from the region-ordered numbering (every run is contiguous) plus pack/unpack launches (brk_exchange_*).  The names exist
+  // so that code calling them fails at run time with an explanation instead of at link time.
+  static BrickStorage mmap_alloc(long, long) {
+    throw std::runtime_error("BrickStorage::mmap_alloc: mmap views are not part of the MI355X brick engine; allocate with "
+                             "BrickStorage::allocate / movBrickStorage and exchange with BrickDecomp::exchangeView (brk_exchange_*)");
+  }
+  static BrickStorage mmap_alloc(long chunks, long step, void *, size_t) { return mmap_alloc(chunks, step); }
 };
 
 // Adjacency list: adj[b][3^dims]; entry (dk+1)*9+(dj+1)*3+(di+1) for dims == 3, centre = self.

@@ -144,6 +144,23 @@ def test_example_driver_runs():
     assert "dev_shl: ok" in out2, out2
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_cpp_weak_driver_exchange_views():
+    """examples/weak_hip.cpp: the reference's weak driver shape in C++ -- BrickDecomp + populate_cart, ExchangeView /
+    MultiStageExchangeView / bDecomp.exchange(bStorage) of include/brick-mpi.h over the C-ABI exchange (device links, and the
+    same runs through a 1-rank RCCL communicator), brick_func timed with time_mpi of include/bricktime.h, mmap_alloc refusing."""
+    exe = os.path.join(ROOT, "examples", "weak_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    r = subprocess.run([exe, "64"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out
+    assert "weak_hip: all exchanges match" in out and "ghost mismatch" not in out, out
+    assert out.count("ghosts match") == 7 and "over RCCL" in out and "mmap_alloc: refused" in out, out
+    assert "GStencil/s" in out
+
+
 @pytest.mark.parametrize("dims", [(32, 24, 16), (16, 16, 16), (64, 40, 48)])
 def test_mpi_side_headers(tmp_path, dims):
     """include/bitset.h, zmort.h and brick-mpi.h (BitSet, ZMORT, BrickDecomp<3,8,8,8>, skin3d_good, allneighbors,
@@ -175,6 +192,42 @@ def test_mpi_side_headers(tmp_path, dims):
     assert int(kv["adjhash"][0]) == h
     rm = populate(d, [2, 2, 2], [1, 0, 1])
     assert [int(x) for x in kv["ranks"]] == [rm[n] for n in allneighbors()]
+
+
+def test_bricktime_and_views_compile_without_mpi(tmp_path):
+    """include/bricktime.h (time_func / time_mpi; hiptime_func needs hipcc) and the ExchangeView API of brick-mpi.h with no MPI
+    in sight: a host-only translation unit compiles and links against libbrk.so, and time_func follows the doubling protocol."""
+    src = tmp_path / "t.cpp"
+    src.write_text('''
+#define BRK_NO_MPI
+#define TOT_TIME 0.05
+#include <brick-mpi.h>
+#include <bricktime.h>
+#include <cstdio>
+int MPI_ITER = 3;
+int main() {
+  BrickDecomp<3, 8, 8, 8> d({32, 32, 32}, 8);
+  d.initialize(skin3d_good);
+  const int cart[3] = {1, 1, 1}, coo[3] = {0, 0, 0};
+  populate_cart(d, cart, coo);
+  int calls = 0, cnt = 0;
+  double s = time_func([&] { ++calls; });
+  double m = time_mpi([&] { ++calls; }, cnt, d);
+  // 1 warm-up + 1 + 2 + 4 + ... calls, then 1 warm-up + MPI_ITER
+  int batches = calls - 1 - 4;
+  bool pow2m1 = ((batches + 1) & batches) == 0;
+  printf("%d %d %d %d\\n", cnt, pow2m1 ? 1 : 0, s >= 0 ? 1 : 0, m >= 0 ? 1 : 0);
+  try { BrickStorage::mmap_alloc(1, 512); } catch (const std::runtime_error &) { printf("refused\\n"); }
+  ExchangeView (BrickDecomp<3, 8, 8, 8>::*fn)(const BrickStorage &, int, unsigned) const = &BrickDecomp<3, 8, 8, 8>::exchangeView;
+  return fn == nullptr;
+}
+''')
+    csrc = os.path.join(ROOT, "bricklib_amd", "csrc")
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", csrc, "-lbrk",
+                           "-Wl,-rpath," + csrc])
+    out = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE).stdout.decode().split()
+    assert out == ["3", "1", "1", "1", "refused"], out
 
 
 def test_brick_mpi_header_with_mpi(tmp_path):
