@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--n", "--cells", dest="n", type=int, default=512, help="cells per axis per GPU (default 512 = BASELINE config)")
     ap.add_argument("--stencil", default=None, help="override stencil (7pt|27pt|mpi7pt|mpi13pt|mpi25pt|mpi125pt)")
+    ap.add_argument("--variant", type=int, default=0, help="experiments: kernel variant of the chosen stencil (brk_set_variant; 0 = default)")
     ap.add_argument("--workload", default=None, choices=[None, "single", "weak", "strong"],
                     help="single = 7-pt sweep of one 512^3 grid (default at 1 GPU); weak = 512^3 per rank with ghost exchange "
                          "(default at N>1); strong = fixed global --strong-dom^3 cut into --strong-sub^3 subdomains (config 5)")
@@ -140,14 +141,22 @@ def cpu_baseline(O, sid, info, st, step, ids, coeff, n_cells, seconds):
                       f"(OpenMP, {cores} threads), {dt:.1f} s"}
 
 
-def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, launches=50, nsample=512):
+def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, launches=100, nsample=512, warm_ms=150.0):
     """One of the other stencils of BASELINE configs 2-3 on the SAME 512^3 grid through the same box entry point, outside
     the timed headline: kernel time from HIP events on the launch stream, roofline fraction, sampled oracle check."""
     from bricklib_amd.stencils import STENCILS
     sid = STENCILS[name]
     coeff = np.random.default_rng(1).random(129) if name in ("7pt", "27pt") else None
     bIn, bOut = bl.Brick(info, st, 0), bl.Brick(info, sto, off_out)
-    for _ in range(5):
+    # the sampled oracle check of the previous stencil leaves the GPU idle for seconds: warm up until the clocks are back
+    # (>= warm_ms of back-to-back launches) before the timed launches
+    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    w0.record(stream)
+    for _ in range(20):
+        bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream)
+    w1.record(stream)
+    torch.cuda.synchronize()
+    for _ in range(int(warm_ms / max(w0.elapsed_time(w1) / 20, 1e-3))):
         bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
@@ -172,6 +181,9 @@ def run_single(args, bl, dev):
     N = args.n
     name = args.stencil or "7pt"
     sid = STENCILS[name]
+    if args.variant:
+        from bricklib_amd._lib import check, lib
+        check(lib.brk_set_variant(sid, args.variant))
     K = args.steps if args.steps is not None else 200
     W = args.warmup if args.warmup is not None else 20
     SB = (N + 16) // 8
@@ -221,7 +233,7 @@ def run_single(args, bl, dev):
     order = sorted(range(len(wins)), key=lambda q: wins[q][0])
     wall, kern_ms = wins[order[len(order) // 2]]
     cells = float(N) ** 3
-    res = {"workload": f"single-{name}-{N}", "layout": args.layout, "form": args.form, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+    res = {"workload": f"single-{name}-{N}" + (f"-variant{args.variant}" if args.variant else ""), "layout": args.layout, "form": args.form, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
            "kernel": "%s over %d bricks" % ("k_s7_wg<8 waves>" if name in ("7pt", "mpi7pt") else ("k_star_wg" if name in ("mpi13pt", "mpi25pt") else "k_cube_dense"), ids.size)}
     extra = {"timing": {"protocol": "median of %d windows of %d launches, each between two device synchronisations" % (len(wins), K),
@@ -264,6 +276,14 @@ def run_single(args, bl, dev):
         for nm in ("27pt", "mpi125pt", "mpi13pt", "mpi25pt"):
             if nm != name:
                 blk[nm] = side_stencil(bl, O, nm, info, st, sto, step_e, off_out, ids, box, stream)
+        try:      # HBM-side traffic per launch of these kernels from the committed PMC passes (static, like roofline.traffic)
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_by_stencil.json")))
+            for nm in blk:
+                if N == 512 and nm in pt["traffic_bytes_per_launch"]:
+                    blk[nm]["roofline"]["traffic"] = pt["traffic_bytes_per_launch"][nm]
+                    blk[nm]["roofline"]["traffic_source"] = "profiles/pmc_traffic_by_stencil.json"
+        except Exception:
+            pass
         extra["config3"] = {"workload": "single-{27pt,mpi125pt}-%d (+ 13/25-point), same box entry point" % N, **blk}
     if O is not None and not args.no_cpu_baseline:
         try:
