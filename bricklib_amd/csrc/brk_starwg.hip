@@ -94,24 +94,39 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     STAMPW(t2); // adjacency + list neighbours known (own planes in flight)
     const gcptr p_km = sbase(in + (size_t)n_km * step), p_kp = sbase(in + (size_t)n_kp * step);
     const gcptr p_jm = sbase(in + (size_t)n_jm * step), p_jp = sbase(in + (size_t)n_jp * step);
-    double fjm[R], fjp[R], fim[R], fip[R];
+    // Every 128-byte line is requested by ONE instruction of this wave.  A j-face is R rows of 64 B per k-plane = R/2 whole
+    // lines: lane (k, c) takes 16 B of it per instruction (8 lanes = one line), R/2 instructions on disjoint lines.  The first
+    // form of this kernel took one row per instruction, lane (k, i): rows 2q and 2q+1 share a line, so the second request hit a
+    // line whose miss was still pending -- the L1 stalls on that (TCP_PENDING_STALL_CYCLES: 70 % of the kernel's cycles in
+    // profiles/r02_c_pmc_27pt_list_mem.txt) and every other wave's requests wait behind it.
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) d2 *gc2;
+    constexpr int H = R / 2;
+    d2 fjm[H], fjp[H], fim[H], fip[H];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       col[r] = p_km[(8 - R + r) * 64 + lane];
       col[R + 8 + r] = p_kp[r * 64 + lane];
-      fjm[r] = p_jm[hi * 64 + (8 - R + r) * 8 + lo]; // lane = (k, i): row 8-R+r of the -j brick
-      fjp[r] = p_jp[hi * 64 + r * 8 + lo];
-      fim[r] = fip[r] = 0.0;
     }
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      fjm[q] = *(gc2)(p_jm + hi * 64 + (8 - R) * 8 + q * 16 + 2 * lo); // rows 8-R+2q, 8-R+2q+1 of the -j brick, plane k = hi
+      fjp[q] = *(gc2)(p_jp + hi * 64 + q * 16 + 2 * lo);               // rows 2q, 2q+1 of the +j brick
+      fim[q] = fip[q] = d2{0.0, 0.0};
+    }
+    // i-faces (only without a sibling): the R halo columns of a (k, j) row are R x 8 contiguous bytes.  R = 2: lane (k, j) takes
+    // the 16 B in one instruction.  R = 4: 32 B per row; instruction q takes the planes 4q..4q+3 with lane (k, j, half), so the
+    // two instructions touch disjoint lines.
+    const int ik = R == 2 ? hi : (lane >> 4), ij = R == 2 ? lo : ((lane >> 1) & 7), ih = R == 2 ? 0 : (lane & 1);
     if (!share_im) {
       const gcptr p_im = sbase(in + (size_t)n_im * step);
 #pragma unroll
-      for (int r = 0; r < R; ++r) fim[r] = p_im[hi * 64 + lo * 8 + (8 - R + r)]; // lane = (k, j): column 8-R+r
+      for (int q = 0; q < H; ++q) fim[q] = *(gc2)(p_im + (ik + 4 * q) * 64 + ij * 8 + (8 - R) + 2 * ih);
     }
     if (!share_ip) {
       const gcptr p_ip = sbase(in + (size_t)n_ip * step);
 #pragma unroll
-      for (int r = 0; r < R; ++r) fip[r] = p_ip[hi * 64 + lo * 8 + r];
+      for (int q = 0; q < H; ++q) fip[q] = *(gc2)(p_ip + (ik + 4 * q) * 64 + ij * 8 + 2 * ih);
     }
     STAMPW(t3); // everything requested
 #ifdef BRK_STAMP_SW
@@ -129,17 +144,23 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
 #pragma unroll
     for (int k = 0; k < 8; ++k) tile[k * TL::PLANE + (hi + R) * 8 + lo] = col[R + k];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      tile[hi * TL::PLANE + r * 8 + lo] = fjm[r];
-      tile[hi * TL::PLANE + (R + 8 + r) * 8 + lo] = fjp[r];
+    for (int q = 0; q < H; ++q) { // rows 2q + lo/4, columns 2(lo%4), +1: 16 aligned bytes of the tile
+      *(d2 *)&tile[hi * TL::PLANE + (2 * q) * 8 + 2 * lo] = fjm[q];
+      *(d2 *)&tile[hi * TL::PLANE + (R + 8 + 2 * q) * 8 + 2 * lo] = fjp[q];
     }
     if (!share_im) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) tile[hi * TL::PLANE + TL::IM + r * 8 + lo] = fim[r];
+      for (int q = 0; q < H; ++q) { // fallback slots [r][j] of plane k
+        tile[(ik + 4 * q) * TL::PLANE + TL::IM + (2 * ih) * 8 + ij] = fim[q].x;
+        tile[(ik + 4 * q) * TL::PLANE + TL::IM + (2 * ih + 1) * 8 + ij] = fim[q].y;
+      }
     }
     if (!share_ip) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) tile[hi * TL::PLANE + TL::IP + r * 8 + lo] = fip[r];
+      for (int q = 0; q < H; ++q) {
+        tile[(ik + 4 * q) * TL::PLANE + TL::IP + (2 * ih) * 8 + ij] = fip[q].x;
+        tile[(ik + 4 * q) * TL::PLANE + TL::IP + (2 * ih + 1) * 8 + ij] = fip[q].y;
+      }
     }
   }
   __syncthreads(); // sibling tiles are readable
