@@ -59,10 +59,11 @@ def parse():
                     help="weak workload, runs that leave the GPU: packed = one RCCL send+recv per peer through pack/unpack "
                          "kernels, direct = one per run straight from the storage (the reference's zero-copy form), shift = "
                          "three-stage shift exchange, <= 2 messages per stage (MultiStageExchangeView)")
-    ap.add_argument("--transport", default="abi", choices=("abi", "torch"),
+    ap.add_argument("--transport", default="auto", choices=("auto", "abi", "torch"),
                     help="N > 1, messages that leave the GPU: abi = ncclGroupStart/ncclSend/ncclRecv/ncclGroupEnd issued inside libbrk.so "
                          "(brk_exchange_transport) on a communicator created through the C ABI, bootstrapped over the torch.distributed "
-                         "group; torch = the same messages as torch.distributed batch_isend_irecv (backend nccl = RCCL)")
+                         "group; torch = the same messages as torch.distributed batch_isend_irecv (backend nccl = RCCL); auto = abi, "
+                         "unless creating that communicator fails on any rank (decided collectively, before any data moves): then torch")
     ap.add_argument("--self-via-comm", action="store_true",
                     help="weak workload on ONE GPU: send the self-neighbour runs through a 1-rank RCCL communicator (ncclSend/ncclRecv "
                          "to self inside libbrk.so) instead of device links -- exercises the whole pack -> RCCL -> unpack path, on the "
@@ -173,6 +174,34 @@ def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, 
     if O is not None:
         r["max_abs_err_vs_oracle"] = verify_sample(bl, O, sid, info, st, sto, step_e, off_out, ids, coeff, nsample=nsample)
     return r
+
+
+def make_comm(args, world, dev):
+    """The RCCL communicator of the C-ABI transport (bricklib_amd.decomp.Comm), or None for the torch transport.
+    rank 0's ncclUniqueId travels over the torch.distributed group; after that torch is not in the data path.  With
+    --transport auto a failure to create it on ANY rank (librccl not loadable, ncclCommInitRank error) makes EVERY rank fall back
+    to the torch transport: the ranks agree through an all-reduce before any data moves."""
+    if world == 1 or args.backend != "nccl" or args.transport == "torch":
+        return None
+    import torch.distributed as dist
+    from bricklib_amd.decomp import Comm
+    comm, err = None, None
+    try:
+        comm = Comm.bootstrap()
+    except Exception as e:           # BrkError from libbrk.so, or a failed broadcast
+        if args.transport == "abi":
+            raise
+        err = e
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return comm
+    if args.transport == "abi":
+        raise RuntimeError("the C-ABI RCCL communicator could not be created on every rank")
+    sys.stderr.write(f"bench.py: C-ABI communicator unavailable on some rank ({err!r} here): all ranks use the torch transport\n")
+    if comm is not None:
+        comm.destroy()
+    return None
 
 
 def run_single(args, bl, dev):
@@ -310,11 +339,8 @@ def run_weak(args, bl, dev, rank, world):
     stA, stB = info.allocate(512, dev), info.allocate(512, dev)
     stA.dat.uniform_(0.0, 1.0)
     A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
-    comm = None
-    if world > 1 and args.backend == "nccl" and args.transport == "abi":
-        from bricklib_amd.decomp import Comm
-        comm = Comm.bootstrap()              # rank 0's ncclUniqueId travels over the torch.distributed group; then RCCL only
-    elif world == 1 and args.self_via_comm:
+    comm = make_comm(args, world, dev)
+    if comm is None and world == 1 and args.self_via_comm:
         from bricklib_amd.decomp import Comm
         comm = Comm.init_rank(Comm.unique_id(), 0, 1)
     ex = Exchanger(d, stA, rank, mode=args.exchange, staged=args.backend == "gloo" and world > 1, comm=comm,
@@ -512,10 +538,8 @@ def run_strong(args, bl, dev, rank, world):
     comm = None
     if args.backend == "gloo":
         transport = staged_transport
-    elif world > 1 and args.transport == "abi":
-        from bricklib_amd.decomp import Comm
+    elif world > 1 and (comm := make_comm(args, world, dev)) is not None:
         from bricklib_amd.strong import rccl_transport
-        comm = Comm.bootstrap()
         transport = rccl_transport(comm)
     else:
         transport = nccl_transport
