@@ -207,8 +207,17 @@ extern "C" void brk_exchange_view_free(brk_exchange_view *v) {
   delete v;
 }
 
+// a view's buffers and link tables live on the device it was created on
+static int check_device(const brk_exchange_view *v) {
+  int cur = -1;
+  HIP_TRY(hipGetDevice(&cur));
+  if (cur != v->device) return brk_fail(BRK_EINVAL, "exchange: view belongs to device %d, current device is %d", v->device, cur);
+  return BRK_OK;
+}
+
 static int run_phase(brk_exchange_view *v, uint32_t stage, int ph, brk_stream s) {
   if (!v || stage >= v->nstages) return brk_fail(BRK_EINVAL, "exchange: bad view / stage");
+  if (int rc = check_device(v)) return rc;
   const brk_exchange_view::Stage &S = v->stages[stage];
   if (!S.n[ph]) return BRK_OK;
   return brk_link_copy(v->links_dev + S.off[ph], S.n[ph], S.max_bytes[ph], s);
@@ -222,6 +231,7 @@ extern "C" int brk_exchange_transport(brk_exchange_view *v, uint32_t stage, void
   const brk_exchange_view::Stage &S = v->stages[stage];
   if (S.msgs.empty()) return BRK_OK;
   if (!comm) return brk_fail(BRK_EINVAL, "exchange: %zu messages to move but no communicator", S.msgs.size());
+  if (int rc = check_device(v)) return rc;
   Rccl *R = rccl();
   if (!R) return rccl_missing();
   hipStream_t st = static_cast<hipStream_t>(s);

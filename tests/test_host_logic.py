@@ -162,6 +162,63 @@ def test_strong_ownership_matches_reference_under_mpi(oracle, golden):
             assert oracle.strong_getrank(int(nset), int(zid), subdim, n) == (int(znew), int(dst), int(sub))
 
 
+def test_exchange_plans_host_side(oracle):
+    """brk_xplan_*: plans are host bookkeeping (no GPU): every ghost brick of every rank is written exactly once by the copies
+    of a packed / direct / shift plan, sends and receives of all ranks pair up message by message, error paths report."""
+    from bricklib_amd.decomp import SP_RECV, SP_SEND, SP_STORAGE, XPlan, populate, rank_to_coo
+    dom = (32, 16, 24)
+    for world in (1, 2, 3, 8):
+        cart = bl.dims_create(world)
+        for mode in ("packed", "direct", "shift"):
+            plans = []
+            for r in range(world):
+                d = bl.BrickDecomp(dom)
+                populate(d, cart, rank_to_coo(r, cart))
+                plans.append((d, XPlan.from_decomp(d, r, mode, 512)))
+            for r, (d, p) in enumerate(plans):
+                assert p.my_rank == r and p.nstages == (3 if mode == "shift" else 1)
+                # bytes landing in the storage: each ghost brick exactly once over all stages (copies into storage + direct receives)
+                hits = np.zeros(d.nbricks, dtype=np.int32)
+                for c in p.copies:
+                    if c["dst_space"] == SP_STORAGE:
+                        assert c["dst_off"] % 4096 == 0 and c["bytes"] % 4096 == 0
+                        hits[c["dst_off"] // 4096:(c["dst_off"] + c["bytes"]) // 4096] += 1
+                for m in p.msgs:
+                    if not m["is_send"] and m["space"] == SP_STORAGE:
+                        hits[m["off"] // 4096:(m["off"] + m["bytes"]) // 4096] += 1
+                assert (hits[d.sep_pos[1]:d.sep_pos[2]] == 1).all() and hits[:d.sep_pos[1]].sum() == 0, (world, mode, r)
+                # every send has its receive on the peer, in order, with the same size
+                for st in range(p.nstages):
+                    for peer in p.peers(st):
+                        mine = [m["bytes"] for m in p.msgs if m["stage"] == st and m["is_send"] and m["peer"] == peer]
+                        theirs = [m["bytes"] for m in plans[peer][1].msgs if m["stage"] == st and not m["is_send"] and m["peer"] == r]
+                        assert mine == theirs, (world, mode, r, peer, st)
+                        if mode != "direct":
+                            assert len(mine) <= 1 and p.buffer_bytes(st, peer, SP_SEND) == sum(mine)
+                            assert plans[peer][1].buffer_bytes(st, r, SP_RECV) == sum(mine)
+                if mode == "packed":
+                    assert len(p.peers()) <= 7
+                if mode == "shift":
+                    assert sum(1 for m in p.msgs if m["is_send"]) <= 6
+    # error paths
+    d = bl.BrickDecomp(dom)
+    populate(d, [1, 1, 1], [0, 0, 0])
+    ranks = (C.c_int * 27)(*[0] * 27)
+    h = C.c_void_p()
+    assert lib.brk_xplan_build_decomp(d._h, ranks, 0, 7, 0, 512, C.byref(h)) != 0 and b"mode" in lib.brk_last_error()
+    assert lib.brk_xplan_build_decomp(d._h, ranks, -1, 0, 0, 512, C.byref(h)) != 0
+    assert lib.brk_xplan_build_decomp(d._h, ranks, 0, 0, 0, 100, C.byref(h)) != 0
+    bad = dict(stage=0, phase=0, src_space=SP_STORAGE, dst_space=SP_SEND, src_peer=-1, dst_peer=1, src_off=8, dst_off=0, bytes=4096)
+    with pytest.raises(bl.BrkError, match="multiples of 16"):
+        XPlan.from_tables(0, [bad], [])
+    with pytest.raises(bl.BrkError, match="receive buffer"):
+        XPlan.from_tables(0, [dict(bad, src_off=0, dst_space=SP_RECV)], [])
+    with pytest.raises(bl.BrkError, match="sends leave from send buffers"):
+        XPlan.from_tables(0, [], [dict(stage=0, is_send=1, peer=1, space=SP_RECV, off=0, bytes=4096)])
+    ok = XPlan.from_tables(2, [dict(bad, src_off=0)], [dict(stage=0, is_send=1, peer=1, space=SP_SEND, off=0, bytes=4096)])
+    assert ok.bytes_remote == 4096 and ok.buffer_bytes(0, 1, SP_SEND) == 4096 and ok.my_rank == 2
+
+
 def test_exchange_plan_covers_ghost_once():
     d = bl.BrickDecomp((32, 32, 32))
     covered = np.zeros(d.nbricks, dtype=np.int32)
