@@ -767,6 +767,55 @@ def test_taps_argument_checks(dev):
             apply_taps(bad, bl.Brick(info, st, 0), bl.Brick(info, so, 0), brick_range=(0, 1))
 
 
+def test_entry_point_edge_cases(oracle, dev):
+    """empty and degenerate inputs, and the error convention of the hot-path entry points (return code + brk_last_error, nothing
+    written): empty list / empty range / empty box are no-ops; in == out, step < 512, reversed ranges, boxes outside the
+    numbering, unknown stencils and missing coefficient vectors are refused."""
+    from bricklib_amd._lib import lib
+    from bricklib_amd.brick import _ptr
+    grid, info = bl.init_grid((5, 5, 5), dev)
+    st, so = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(2))
+    st.dat.uniform_(0.0, 1.0)
+    A, B = bl.Brick(info, st, 0), bl.Brick(info, so, 0)
+    empty = torch.zeros(0, dtype=torch.int32, device=dev)
+    for name in ("7pt", "mpi7pt", "mpi13pt", "mpi25pt", "27pt", "mpi125pt", "mpi7pt_x2"):
+        coeff = oracle.coeffs(129, 1) if name in ("7pt", "27pt") else None
+        bl.apply_stencil(name, A, B, brick_range=(7, 7), coeff=coeff)                       # empty range
+        bl.apply_stencil(name, A, B, box=(0, (5, 5, 5), (1, 1, 1), (3, 0, 3)), coeff=coeff)   # empty box
+        assert lib.brk_stencil_apply_list(bl.STENCILS[name], _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, None, 0, None, None) in (0, -1)
+        # a single brick, through every form
+        b = int(grid.reshape(5, 5, 5)[2, 2, 2])
+        want = np.zeros(info.nbricks * 512)
+        oracle.brick_stencil(NAMES[name[:-3] if name.endswith("_x2") else name], info.adj_host, st.dat.cpu().numpy(), want, 512,
+                             ids=np.array([b], dtype=np.uint32), coeff=coeff)
+        if not name.endswith("_x2"):
+            for kw in (dict(brick_range=(b, b + 1)), dict(ids=grid_to_device(np.array([b], dtype=np.uint32), dev)),
+                       dict(box=(0, (5, 5, 5), (2, 2, 2), (1, 1, 1)))):
+                so.dat.zero_()
+                bl.apply_stencil(name, A, B, coeff=coeff, **kw)
+                got = so.dat.cpu().numpy()
+                assert np.abs(got - want).max() <= TOL, (name, kw.keys())
+    assert (so.dat.view(-1, 512)[0] == 0).all()
+    so.dat.zero_()
+    U3 = C.c_uint32 * 3
+    cases = [
+        lambda: lib.brk_stencil_apply_range(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(st.dat), 512, 1, 2, None, None),     # in == out
+        lambda: lib.brk_stencil_apply_range(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 256, 1, 2, None, None),     # step < 512
+        lambda: lib.brk_stencil_apply_range(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, 5, 2, None, None),     # reversed
+        lambda: lib.brk_stencil_apply_range(bl.BRK_7PT_COEFF, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, 1, 2, None, None),  # no coefficients
+        lambda: lib.brk_stencil_apply_range(42, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, 1, 2, None, None),               # unknown stencil
+        lambda: lib.brk_stencil_apply_list(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, None, 3, None, None),     # null list
+        lambda: lib.brk_stencil_apply_box(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, 0, U3(5, 5, 5), U3(3, 3, 3), U3(3, 1, 1), None, None),
+        lambda: lib.brk_stencil_apply_range(bl.BRK_MPI7, None, _ptr(st.dat), _ptr(so.dat), 512, 1, 2, None, None),                # null adjacency
+        lambda: lib.brk_link_copy(None, 3, 4096, None),
+        lambda: lib.brk_exchange_view_create(None, _ptr(st.dat), C.byref(C.c_void_p())),
+    ]
+    for q, f in enumerate(cases):
+        assert f() < 0 and len(lib.brk_last_error()) > 0, q
+    torch.cuda.synchronize()
+    assert (so.dat == 0).all()                      # nothing was launched by a refused call
+
+
 def test_box_list_cache_replacement(oracle, dev):
     """more box geometries than the library caches id lists for (8): entries are replaced and rebuilt correctly"""
     shape = (12, 11, 10)
