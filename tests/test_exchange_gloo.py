@@ -44,7 +44,7 @@ def _worker(rank, world, port, dom, q, mode):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "direct"), (4, "direct"), (2, "packed"), (4, "packed"), (8, "packed"), (8, "direct"), (2, "shift"),
-                                        (4, "shift"), (8, "shift"), (3, "shift")])
+                                        (4, "shift"), (8, "shift"), (3, "shift"), (3, "packed"), (6, "direct")])
 def test_exchange_two_ranks_gloo(oracle, world, mode):
     dom = (32, 16, 24)
     port = 29500 + (os.getpid() % 2000) + world + {"direct": 0, "packed": 10, "shift": 20}[mode]

@@ -897,3 +897,33 @@ def test_fused_double_sweep(oracle, dev, name):
     bl.apply_stencil(name, Bd(M), Bd(T2), brick_range=(1, d.sep_pos[1]), coeff=coeff)
     bl.apply_stencil(name + "_x2", Bd(A), Bd(F), brick_range=(1, d.sep_pos[1]), coeff=coeff)
     assert (T2.dat[512:512 * d.sep_pos[1]] - F.dat[512:512 * d.sep_pos[1]]).abs().max().item() <= TOL
+
+
+@pytest.mark.timeout(600)
+def test_bench_line_contract_small():
+    """bench.py end to end at a small size: ONE JSON line with the contract's keys (metric, value, steps, roofline with
+    bound/achieved/peak/frac, cpu_baseline, config with a workload name), the round-2 additions (timing windows, steady state,
+    config3 block with per-stencil roofline and oracle error), and a sampled oracle error within the parity bar."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cells", "128", "--steps", "5", "--warmup", "2", "--windows", "3",
+                        "--steady-seconds", "0.2", "--cpu-seconds", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=560)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["dtype"] == "f64" and d["config"]["workload"] == "single-7pt-128"
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert len(d["timing"]["window_ms_per_step"]) == 3 and d["steady_state"]["launches"] > 0
+    assert d["max_abs_err_vs_oracle"] <= TOL
+    for nm in ("27pt", "mpi125pt", "mpi13pt", "mpi25pt"):
+        assert d["config3"][nm]["max_abs_err_vs_oracle"] <= TOL and d["config3"][nm]["roofline"]["frac"] > 0
+    assert d["weak_workload_on_this_gpu"]["value"] > 0
