@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/{populate_ranks,strong_getrank,dims_create}.npz from the REFERENCE run under MPI.
+"""Generate tests/golden/{populate_ranks,strong_getrank,dims_create,weak_cycle_ref}.npz from the REFERENCE run under MPI.
 
 TEST INFRASTRUCTURE ONLY.  Needs the build container: /root/reference, conda MPICH (mpiexec) and
 `make -C oracle refmpi` (oracle/_ref/ref_mpi_tables = the reference's populate() from include/brick-mpi.h:730-753,
@@ -60,9 +60,27 @@ def main():
         arrs_s[f"getrank_{n}_{d}_{s}"] = g
     # ---- MPI_Dims_create(n, 3)
     dm = np.array([[int(x) for x in l[1:5]] for l in run(1, "dims") if l and l[0] == "D"], dtype=np.int32)
+    # ---- one arr_func of the reference's weak driver (exchangeArr + ST_ITER sweeps of ST_CPU) on 1, 2 and 8 ranks, 16^3 per rank:
+    # pins the multi-rank composition (neighbour orientation of populate, ghost exchange, sweep schedule with the skipped
+    # outer ring) that the weak-cycle tests reproduce with the oracle on a global periodic array
+    import tempfile
+    arrs_w = {"seed": np.array([42], dtype=np.uint64), "cells": np.array([16], dtype=np.int32)}
+    for st in (7, 13, 25, 125):
+        exe = os.path.join(ROOT, "oracle", "_ref", f"ref_mpi_weak_{st}")
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "refweak"])
+        for n in (1, 2, 8):
+            with tempfile.TemporaryDirectory() as td:
+                subprocess.run([MPIEXEC, "-np", str(n), exe, "16", "42", os.path.join(td, "w")], env=ENV, check=True, timeout=600)
+                for r in range(n):
+                    raw = open(os.path.join(td, f"w_np{n}_r{r}.bin"), "rb").read()
+                    hdr = np.frombuffer(raw[:64], dtype=np.int64)
+                    assert hdr[0] == n and hdr[1] == r
+                    arrs_w[f"hdr_{st}_{n}_{r}"] = hdr.copy()
+                    arrs_w[f"out_{st}_{n}_{r}"] = np.frombuffer(raw[64:], dtype=np.float64).reshape(16, 16, 16).copy()
     man_path = os.path.join(OUT, "MANIFEST.json")
     manifest = json.load(open(man_path)) if os.path.exists(man_path) else {}
-    for name, a in (("populate_ranks", arrs_p), ("strong_getrank", arrs_s), ("dims_create", {"n_dims": dm})):
+    for name, a in (("populate_ranks", arrs_p), ("strong_getrank", arrs_s), ("dims_create", {"n_dims": dm}), ("weak_cycle_ref", arrs_w)):
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **a)
         manifest[name] = {k: sha(v) for k, v in a.items()}
         print(name, {k: v.shape for k, v in list(a.items())[:4]}, "...")

@@ -175,10 +175,20 @@ def test_weak_cycle_deep_schedule_virtual_ranks(oracle, dev, name, nranks):
     _weak_virtual(oracle, dev, name, nranks, (40, 32, 48), "deep")
 
 
-def _weak_virtual(oracle, dev, name, nranks, dom, schedule):
+@pytest.mark.parametrize("name,st", [("mpi7pt", 7), ("mpi13pt", 13), ("mpi25pt", 25), ("mpi125pt", 125), ("mpi7pt_x2", 7)])
+@pytest.mark.parametrize("nranks", [1, 2, 8])
+def test_weak_cycle_vs_reference_run_under_mpi(oracle, golden, dev, name, st, nranks):
+    """the HIP weak cycle (exchange + ST_ITER sweeps, `nranks` virtual ranks on this GPU) against what the REFERENCE's weak driver
+    produced for the same global field under mpiexec -np {1,2,8} (tests/golden/weak_cycle_ref.npz: exchangeArr + ST_CPU sweeps,
+    oracle/ref_mpi_weak.cpp); the fused double-sweep cycle against the same 7-point fixture."""
+    z = golden("weak_cycle_ref")
+    _weak_virtual(oracle, dev, name, nranks, (16, 16, 16), "lists", seed=int(z["seed"][0]), ncycles=1,
+                  ref={r: z[f"out_{st}_{nranks}_{r}"] for r in range(nranks)})
+
+
+def _weak_virtual(oracle, dev, name, nranks, dom, schedule, seed=11, ncycles=2, ref=None):
     cart = bl.dims_create(nranks)
     gdims = [cart[2 - a] * dom[a] for a in range(3)]
-    seed = 11
     d = bl.BrickDecomp(dom)
     info = d.getBrickInfo(dev)
     gdev = grid_to_device(d.grid.reshape(-1), dev)
@@ -196,7 +206,6 @@ def _weak_virtual(oracle, dev, name, nranks, dom, schedule):
     assert not remote and len(links) == 42 * nranks
     table = LinkTable(links, dev)
     S = bl.stencil_iters(name)
-    ncycles = 2
     from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
     lists = {"lists": lambda: SweepLists(d, dev), "ranges": lambda: None, "deep": lambda: TrapezoidLists(d, S, dev)}[schedule]()
     if schedule == "deep":
@@ -231,6 +240,9 @@ def _weak_virtual(oracle, dev, name, nranks, dom, schedule):
         bl.copyFromBrick(dom, (0,) * 3, (8,) * 3, got, gdev, bl.Brick(info, stA[r], 0))
         err = np.abs(got[8:-8, 8:-8, 8:-8].cpu().numpy() - want).max()
         assert err <= TOL, (r, err)
+        if ref is not None:              # the reference's own result for this rank (run under MPI)
+            err = np.abs(got[8:-8, 8:-8, 8:-8].cpu().numpy() - ref[r]).max()
+            assert err <= TOL, ("vs reference run", r, err)
 
 
 @pytest.mark.parametrize("variant", [1, 2, 5, 6])
