@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/{populate_ranks,strong_getrank,dims_create,weak_cycle_ref}.npz from the REFERENCE run under MPI.
+"""Generate tests/golden/{populate_ranks,strong_getrank,dims_create,weak_cycle_ref,strong_cycle_ref}.npz from the REFERENCE run under MPI.
 
 TEST INFRASTRUCTURE ONLY.  Needs the build container: /root/reference, conda MPICH (mpiexec) and
 `make -C oracle refmpi` (oracle/_ref/ref_mpi_tables = the reference's populate() from include/brick-mpi.h:730-753,
@@ -78,9 +78,29 @@ def main():
                     assert hdr[0] == n and hdr[1] == r
                     arrs_w[f"hdr_{st}_{n}_{r}"] = hdr.copy()
                     arrs_w[f"out_{st}_{n}_{r}"] = np.frombuffer(raw[64:], dtype=np.float64).reshape(16, 16, 16).copy()
+    # ---- one arr_func of the reference's strong driver (its -v validation path) -- 13-point and 7-point -- on 1, 3 and 8 ranks over
+    # 32^3 in 16^3 subdomains (all 8 subdomains kept), and on 5 ranks over 64^3 in 16^3 subdomains (every 7th of the 64 kept)
+    arrs_g = {"seed": np.array([21], dtype=np.uint64)}
+    for st in (13, 7):
+        exe = os.path.join(ROOT, "oracle", "_ref", f"ref_mpi_strong_{st}")
+        if not os.path.exists(exe):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "refstrong"])
+        for n, d, sd, keep in ((1, 32, 16, 1), (3, 32, 16, 1), (8, 32, 16, 1), (5, 64, 16, 7)):
+            if st == 7 and (n, d) not in ((3, 32), (5, 64)):
+                continue
+            with tempfile.TemporaryDirectory() as td:
+                subprocess.run([MPIEXEC, "-np", str(n), exe, "-d", str(d), "-s", str(sd)], env=dict(ENV, REF_OUT_PREFIX=os.path.join(td, "s")),
+                               check=True, timeout=600, stdout=subprocess.DEVNULL)
+                nsub = (d // sd) ** 3
+                for zid in range(0, nsub, keep):
+                    raw = open(os.path.join(td, f"s_np{n}_z{zid}.bin"), "rb").read()
+                    hdr = np.frombuffer(raw[:64], dtype=np.int64)
+                    assert hdr[0] == n and hdr[2] == zid and hdr[6] == d and hdr[7] == sd
+                    arrs_g[f"hdr_{st}_{n}_{d}_{sd}_{zid}"] = hdr.copy()
+                    arrs_g[f"out_{st}_{n}_{d}_{sd}_{zid}"] = np.frombuffer(raw[64:], dtype=np.float64).reshape(sd, sd, sd).copy()
     man_path = os.path.join(OUT, "MANIFEST.json")
     manifest = json.load(open(man_path)) if os.path.exists(man_path) else {}
-    for name, a in (("populate_ranks", arrs_p), ("strong_getrank", arrs_s), ("dims_create", {"n_dims": dm}), ("weak_cycle_ref", arrs_w)):
+    for name, a in (("populate_ranks", arrs_p), ("strong_getrank", arrs_s), ("dims_create", {"n_dims": dm}), ("weak_cycle_ref", arrs_w), ("strong_cycle_ref", arrs_g)):
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **a)
         manifest[name] = {k: sha(v) for k, v in a.items()}
         print(name, {k: v.shape for k, v in list(a.items())[:4]}, "...")

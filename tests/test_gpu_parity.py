@@ -294,8 +294,23 @@ def test_star7_kernel_variants(oracle, dev, name, variant):
 def test_strong_cycle_virtual_ranks(oracle, dev, name, size):
     """strong/main.cpp shape: 64^3 global domain, 16^3 subdomains in Z-Morton order over `size` ranks (all on one GPU;
     per-peer pack -> loopback -> unpack as transport).  Oracle: the global periodic field swept on the CPU."""
+    _strong_virtual(oracle, dev, name, size, 64, 16, 21, 2)
+
+
+@pytest.mark.parametrize("name,st,size,dom", [("mpi13pt", 13, 1, 32), ("mpi13pt", 13, 3, 32), ("mpi13pt", 13, 8, 32), ("mpi13pt", 13, 5, 64),
+                                              ("mpi7pt", 7, 3, 32), ("mpi7pt", 7, 5, 64)])
+def test_strong_cycle_vs_reference_run_under_mpi(oracle, golden, dev, name, st, size, dom):
+    """the HIP strong cycle (Z-Morton ownership, per-peer pack -> transport -> unpack between `size` virtual ranks, ST_ITER sweeps
+    over all subdomains of a rank in one launch) against what the REFERENCE's strong driver produced for the same global field
+    under mpiexec (tests/golden/strong_cycle_ref.npz: its -v validation path, oracle/ref_mpi_strong.cpp)."""
+    z = golden("strong_cycle_ref")
+    ref = {int(k.split("_")[-1]): z[k] for k in z.files if k.startswith(f"out_{st}_{size}_{dom}_16_")}
+    assert ref
+    _strong_virtual(oracle, dev, name, size, dom, 16, int(z["seed"][0]), 1, ref=ref)
+
+
+def _strong_virtual(oracle, dev, name, size, dom, sdom, seed, ncycles, ref=None):
     from bricklib_amd.strong import StrongRank, loopback_transport
-    dom, sdom, seed = 64, 16, 21
     ranks = [StrongRank(dom, sdom, r, size, dev) for r in range(size)]
     assert sum(sr.nsub for sr in ranks) == (dom // sdom) ** 3
     ext = (sdom + 16,) * 3
@@ -307,7 +322,6 @@ def test_strong_cycle_virtual_ranks(oracle, dev, name, size):
             bl.copyToBrick(ext, (0,) * 3, (0,) * 3, torch.from_numpy(arr).to(dev), sr.grid_dev, sr.sub_brick(0, m))
     transport = loopback_transport(ranks)
     S = bl.stencil_iters(name)
-    ncycles = 2
     for _ in range(ncycles):
         for sr in ranks:
             sr.exchange_begin()
@@ -339,6 +353,9 @@ def test_strong_cycle_virtual_ranks(oracle, dev, name, size):
             bl.copyFromBrick((sdom,) * 3, (0,) * 3, (8,) * 3, got, sr.grid_dev, sr.sub_brick(0, m))
             err = np.abs(got[8:-8, 8:-8, 8:-8].cpu().numpy() - want).max()
             assert err <= TOL, (sr.rank, m, err)
+            if ref is not None and sr.l + m in ref:      # the reference's own result for this subdomain (run under MPI)
+                err = np.abs(got[8:-8, 8:-8, 8:-8].cpu().numpy() - ref[sr.l + m]).max()
+                assert err <= TOL, ("vs reference run", sr.rank, sr.l + m, err)
 
 
 @pytest.mark.parametrize("name", list(NAMES))
