@@ -155,6 +155,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   constexpr int E = TL::ELEMS;
   __shared__ double lds[(NW + 1) * E];
   __shared__ uint32_t breaks[NW];
+  __shared__ double jslot[KIND == kCube125 && PIPE == 5 ? NW * 192 : 1]; // output-side shift slots, one per wave
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
         else if (PIPE == 2) cube125_accumulate_static<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
         else if (PIPE == 3) cube125_accumulate_rows<TL::T * 8, 8, 3>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
         else if (PIPE == 4) cube125_accumulate_rows<TL::T * 8, 8, 5>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
+        else if (PIPE == 5) cube125_accumulate_jout<TL::T * 8, 8>(tile, co, cf, jslot + (PIPE == 5 ? w * 192 : 0), (double *)dst, lane);
         else cube125_accumulate_simple<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
       } else {
         double acc[8];
@@ -360,9 +362,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 
 } // namespace
 
-// variants: 27-pt 0/6 = NW 4 (default), 5 = NW 8; 125-pt 0/10 = NW 4, 3 waves/SIMD, row-pipelined plane loop (default), 11 = the
-// same with 5 rows in flight (spills), 5 = fully unrolled plane loop with static accumulators and one read burst per plane,
-// 9 = the same with the rolled loop over a ring, 6 = NW 4 and 7 = NW 8 with the software-pipelined rolled loop (2 waves/SIMD)
+// variants: 27-pt 0/6 = NW 4 (default), 5 = NW 8; 125-pt 0/12 = NW 4, 3 waves/SIMD, output-side j-shift (default), 10 = input-side
+// row-pipelined plane loop (the default before), 11 = the same with 5 rows in flight (spills), 5 = fully unrolled plane loop with
+// static accumulators and one read burst per plane, 9 = the same with the rolled loop over a ring, 6 = NW 4 and 7 = NW 8 with the
+// software-pipelined rolled loop (2 waves/SIMD)
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8, wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
@@ -381,12 +384,14 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
     hipLaunchKernelGGL((k_cube_dense<kCube125, 8, 2>), dim3(wgs8), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 11) { // row-pipelined plane loop with 5 rows in flight (spills)
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 4>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (variant == 10) { // input-side accumulation, row-pipelined plane loop, 3 rows of LDS reads in flight
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 3>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 9) {
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 0>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 5) { // fully unrolled plane loop, reads of a plane in one burst (the round-1 default)
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 2>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
-  } else { // default (0, 10): row-pipelined plane loop, 3 rows of LDS reads in flight
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 3>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else { // default (0, 12): output-side j-shift -- 60 + 40 LDS reads per lane, the shift through a wave-private slot
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 5>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;

@@ -503,6 +503,84 @@ __device__ __forceinline__ void cube125_accumulate_rows(const double *rowp, cons
   for (int m = 4; m >= 0; --m) fma_chunk(11, m);
 }
 
+// Output-side form of the 125-point accumulation.  The class weights depend on sorted(|di|,|dj|,|dk|) only
+// (stencils/mpi125pt.py:12-33), so
+//   out(k,j,i) = P0(k,j,i) + P1(k,j-1,i) + P1(k,j+1,i) + P2(k,j-2,i) + P2(k,j+2,i),
+//   Pe(k,j',i) = sum over (|di|,|dk|) of c(|di|,e,|dk|) x(k+dk, j', i+di)
+// -- the j-shift is applied ONCE per output to the finished partial sums instead of to every input row.  A lane (j', i)
+// then needs only row j' of each plane: 5 LDS reads per plane, 60 per lane instead of 300, and (with the (|di|,|dk|)
+// fold) 27 fp64 operations per output.  The partial sums are also needed in the four halo rows j' = -2,-1,8,9: 8 k x 4 rows
+// x 8 i = 256 positions = one more pass in which the lower half of the wave takes k = 0..3 and the upper half k = 4..7
+// (40 reads, 100 operations).  The shift itself goes through a 12-row x 8-column slot per e in LDS that only this wave
+// touches (LDS operations of one wave execute in order, so write -> shifted read needs no wait in between): 4 writes and
+// 4 reads per output.  Per lane: ~165 LDS operations and ~375 fp64 operations instead of 300 and 468.
+// `tile` = the wave's dense tile D[12][12][8] (plane pitch PS, row pitch RS); co[d] = offset of column i+d-2 from the row
+// start (own tile or the slot on that side); `slot` = 192 doubles of LDS private to the wave.
+template <int PS, int RS, int NP, bool MAIN, class Emit>
+__device__ __forceinline__ void cube125_jout_stream(const double *rowp, const int (&co)[5], const Coeffs &cf, Emit emit) {
+  constexpr int wa[6] = {0, 1, 2, 0, 0, 1}, wb[6] = {0, 1, 2, 1, 2, 2};
+  double x[2][5]; // rows in flight
+  double V[5][3]; // |di|-folded rows of the last five planes
+  auto load = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int d = 0; d < 5; ++d) x[p & 1][d] = rowp[p * PS + co[d]];
+  };
+  load(0);
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (p + 1 < NP) load(p + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    V[p % 5][0] = x[p & 1][2], V[p % 5][1] = x[p & 1][1] + x[p & 1][3], V[p % 5][2] = x[p & 1][0] + x[p & 1][4];
+    if (p >= 4) { // output p-4: planes p-4 .. p, centre p-2
+      double W[3][3], G[6];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        W[0][d] = V[(p - 2) % 5][d];
+        W[1][d] = V[(p - 3) % 5][d] + V[(p - 1) % 5][d];
+        W[2][d] = V[(p - 4) % 5][d] + V[p % 5][d];
+      }
+      G[0] = W[0][0], G[1] = W[1][1], G[2] = W[2][2];
+      G[3] = W[0][1] + W[1][0], G[4] = W[0][2] + W[2][0], G[5] = W[1][2] + W[2][1];
+      double b[3];
+#pragma unroll
+      for (int e = MAIN ? 0 : 1; e < 3; ++e) {
+        b[e] = cf.c[cls125(e, wa[0], wb[0])] * G[0];
+#pragma unroll
+        for (int q = 1; q < 6; ++q) b[e] += cf.c[cls125(e, wa[q], wb[q])] * G[q];
+      }
+      emit(p - 4, MAIN ? b[0] : 0.0, b[1], b[2]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int PS, int RS>
+__device__ __forceinline__ void cube125_accumulate_jout(const double *tile, const int (&co)[5], const Coeffs &cf, double *slot,
+                                                        double *dst, int lane) {
+  const int hi = lane >> 3, lo = lane & 7;
+  const int kh = lane >> 5, jh = (lane >> 3) & 3;
+  const int hrow = jh < 2 ? jh : jh + 8; // halo rows 0, 1, 10, 11 of the tile
+  double h1[4], h2[4];
+  cube125_jout_stream<PS, RS, 8, false>(tile + kh * 4 * PS + hrow * RS, co, cf,
+                                        [&](int k, double, double b1, double b2) __attribute__((always_inline)) {
+                                          asm volatile("" : "+v"(b1), "+v"(b2)); // computed here, by all lanes, not sunk into the half-wave branch that uses it
+                                          h1[k] = b1, h2[k] = b2;
+                                        });
+  double *s1 = slot + lo, *s2 = slot + 96 + lo;
+  double pb0 = 0.0, r[4] = {0.0, 0.0, 0.0, 0.0};
+  auto retire = [&](int k) __attribute__((always_inline)) { store_result(&dst[k * 64 + lane], pb0 + ((r[0] + r[1]) + (r[2] + r[3]))); };
+  cube125_jout_stream<PS, RS, 12, true>(tile + (hi + 2) * RS, co, cf, [&](int k, double b0, double b1, double b2) __attribute__((always_inline)) {
+    if (k > 0) retire(k - 1);
+    wave_lds_sync(); // the shifted reads of output k-1 stay in front of these writes
+    s1[(hi + 2) * 8] = b1, s2[(hi + 2) * 8] = b2;
+    if (kh == (k >> 2)) s1[hrow * 8] = h1[k & 3], s2[hrow * 8] = h2[k & 3];
+    wave_lds_sync();
+    r[0] = s1[(hi + 1) * 8], r[1] = s1[(hi + 3) * 8], r[2] = s2[hi * 8], r[3] = s2[(hi + 4) * 8];
+    pb0 = b0;
+  });
+  retire(7);
+}
+
 // Load brick `b` (wave-uniform) with its full halo of radius R into `tile` (this wave's private LDS slice of
 // CubeTile<R>::ELEMS doubles): own brick and the 6 faces by structured coalesced loads, edge/corner cells through the
 // descriptor table.

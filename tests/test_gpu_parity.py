@@ -542,7 +542,7 @@ def test_cond_stencil(oracle, golden, dev, variant):
 
 @pytest.mark.parametrize("name,variant", [("27pt", 0), ("27pt", 1), ("27pt", 2), ("27pt", 5), ("mpi125pt", 0), ("mpi125pt", 1),
                                           ("mpi125pt", 3), ("mpi125pt", 4), ("mpi125pt", 5), ("mpi125pt", 6), ("mpi125pt", 7),
-                                          ("mpi125pt", 9), ("mpi125pt", 11),
+                                          ("mpi125pt", 9), ("mpi125pt", 10), ("mpi125pt", 11), ("mpi125pt", 12),
                                           ("mpi13pt", 0), ("mpi13pt", 1), ("mpi13pt", 2), ("mpi25pt", 0), ("mpi25pt", 1),
                                           ("mpi25pt", 2), ("mpi25pt", 3)])
 def test_cube_kernel_variants(oracle, dev, name, variant):
