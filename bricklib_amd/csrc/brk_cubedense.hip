@@ -92,11 +92,14 @@ struct DX {
   }
   static constexpr int IT0 = (count(0) + 63) / 64, ITS = (count(1) + 63) / 64;
   static constexpr int EXTRA_ITERS = IT0 + 2 * ITS;
+  // table layout: four descriptors per lane side by side, so that one 16-byte load brings descriptors 4g .. 4g+3 of a lane
+  static constexpr int QUADS = (EXTRA_ITERS + 3) / 4;
+  __host__ __device__ static constexpr int slot_of(int n) { return ((n / 64 / 4) * 64 + n % 64) * 4 + (n / 64) % 4; }
 };
 
 template <int KIND>
 struct DenseExtra {
-  uint32_t e[DX<KIND>::EXTRA_ITERS * 64];
+  alignas(16) uint32_t e[DX<KIND>::QUADS * 256];
 };
 
 template <int KIND>
@@ -105,7 +108,7 @@ constexpr DenseExtra<KIND> make_dense_extra() {
   using X = DX<KIND>;
   constexpr int R = X::R, T = X::T;
   using TL = DenseTile<KIND>;
-  for (int q = 0; q < X::EXTRA_ITERS * 64; ++q) t.e[q] = 0xFFFFFFFFu;
+  for (int q = 0; q < X::QUADS * 256; ++q) t.e[q] = 0xFFFFFFFFu;
   for (int side = 0; side < 3; ++side) {
     int n = (side == 0 ? 0 : (side == 1 ? X::IT0 : X::IT0 + X::ITS)) * 64;
     for (int kk = 0; kk < T; ++kk)
@@ -118,7 +121,7 @@ constexpr DenseExtra<KIND> make_dense_extra() {
           if ((di < 0 ? 1 : (di > 0 ? 2 : 0)) != side) continue;
           const int sk = (kk - R + 8) % 8, sj = (jj - R + 8) % 8, si = (ii - R + 8) % 8;
           const int col = di < 0 ? 8 - R + ii : (di > 0 ? ii - R - 8 : ii - R);
-          t.e[n++] = (uint32_t)TL::at(kk, jj, col) | ((uint32_t)adj_slot(dk, dj, di) << 16) |
+          t.e[X::slot_of(n++)] = (uint32_t)TL::at(kk, jj, col) | ((uint32_t)adj_slot(dk, dj, di) << 16) |
                      ((uint32_t)(sk * 64 + sj * 8 + si) << 21);
         }
   }
@@ -173,9 +176,15 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   // the descriptors for their addresses, would wait for a full round trip of the brick before they could even be issued.
   uint32_t xd[X::EXTRA_ITERS];
   {
-    const uint32_t *xt = dense_table<KIND>();
+    const uint4 *xt = reinterpret_cast<const uint4 *>(dense_table<KIND>());
 #pragma unroll
-    for (int t = 0; t < X::EXTRA_ITERS; ++t) xd[t] = xt[t * 64 + lane];
+    for (int g = 0; g < X::QUADS; ++g) {
+      const uint4 q = xt[g * 64 + lane];
+      if (4 * g < X::EXTRA_ITERS) xd[4 * g] = q.x;
+      if (4 * g + 1 < X::EXTRA_ITERS) xd[4 * g + 1] = q.y;
+      if (4 * g + 2 < X::EXTRA_ITERS) xd[4 * g + 2] = q.z;
+      if (4 * g + 3 < X::EXTRA_ITERS) xd[4 * g + 3] = q.w;
+    }
   }
   STAMP(t0);
   const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;

@@ -207,6 +207,18 @@ namespace {
 #define STAMP7(var)
 #endif
 
+// load-policy experiments (make EXTRA_HIPFLAGS=-DBRK_NT_OWN / -DBRK_NT_LAST): non-temporal hint on the brick's own planes / on the
+// faces whose lines are not needed again (the bricks below and behind are finished)
+#ifdef BRK_NT_OWN
+#define BRK_LD_OWN(p) __builtin_nontemporal_load(p)
+#else
+#define BRK_LD_OWN(p) (*(p))
+#endif
+#ifdef BRK_NT_LAST
+#define BRK_LD_LAST(p) __builtin_nontemporal_load(p)
+#else
+#define BRK_LD_LAST(p) (*(p))
+#endif
 template <int MPI, int NW, int MODE>
 __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uint32_t *__restrict__ adj,
                                                                       const double *__restrict__ in,
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
     const Nbr nb = load_nbr(adj, b);
     const gcptr self = sbase(in + (size_t)b * step);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) f.own[k] = self[k * 64 + lane];
+    for (int k = 0; k < 8; ++k) f.own[k] = BRK_LD_OWN(&self[k * 64 + lane]);
     __builtin_amdgcn_sched_barrier(0); // own loads are in flight before anything waits for the adjacency row
     // siblings: entry slot-1 / slot+1 when they belong to this workgroup
     share_im = has_prev && __builtin_amdgcn_readfirstlane(nb.im) == b_prev;
@@ -275,9 +287,9 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
       g_stamp7[slot][2] = t2;
     }
 #endif
-    f.km = p_km[7 * 64 + lane];
+    f.km = BRK_LD_LAST(&p_km[7 * 64 + lane]);
     f.kp = p_kp[lane];
-    f.jm = p_jm[hi * 64 + 7 * 8 + lo];
+    f.jm = BRK_LD_LAST(&p_jm[hi * 64 + 7 * 8 + lo]);
     f.jp = p_jp[hi * 64 + lo];
     f.im = 0.0;
     f.ip = 0.0;

@@ -48,7 +48,7 @@ namespace {
 #define STAMPW(var)
 #endif
 
-template <int KIND, int NW, int OCC>
+template <int KIND, int NW, int OCC, int DIAG = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
     const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
@@ -92,8 +92,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     share_im = n_im == b_prev;
     share_ip = n_ip == b_next;
     STAMPW(t2); // adjacency + list neighbours known (own planes in flight)
-    const gcptr p_km = sbase(in + (size_t)n_km * step), p_kp = sbase(in + (size_t)n_kp * step);
-    const gcptr p_jm = sbase(in + (size_t)n_jm * step), p_jp = sbase(in + (size_t)n_jp * step);
+    // DIAG 4 / 8: the k- / j-face loads address the brick itself (same instructions, lines already in the L1): timing experiments
+    const gcptr p_km = sbase(in + (size_t)(DIAG & 4 ? b : n_km) * step), p_kp = sbase(in + (size_t)(DIAG & 4 ? b : n_kp) * step);
+    const gcptr p_jm = sbase(in + (size_t)(DIAG & 8 ? b : n_jm) * step), p_jp = sbase(in + (size_t)(DIAG & 8 ? b : n_jp) * step);
     // Every 128-byte line is requested by ONE instruction of this wave.  A j-face is R rows of 64 B per k-plane = R/2 whole
     // lines: lane (k, c) takes 16 B of it per instruction (8 lanes = one line), R/2 instructions on disjoint lines.  The first
     // form of this kernel took one row per instruction, lane (k, i): rows 2q and 2q+1 share a line, so the second request hit a
@@ -105,13 +106,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     d2 fjm[H], fjp[H], fim[H], fip[H];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      col[r] = p_km[(8 - R + r) * 64 + lane];
-      col[R + 8 + r] = p_kp[r * 64 + lane];
+      col[r] = DIAG & 1 ? 0.25 * r : p_km[(8 - R + r) * 64 + lane]; // DIAG: timing experiments only (wrong results)
+      col[R + 8 + r] = DIAG & 1 ? 0.5 * r : p_kp[r * 64 + lane];
     }
 #pragma unroll
     for (int q = 0; q < H; ++q) {
-      fjm[q] = *(gc2)(p_jm + hi * 64 + (8 - R) * 8 + q * 16 + 2 * lo); // rows 8-R+2q, 8-R+2q+1 of the -j brick, plane k = hi
-      fjp[q] = *(gc2)(p_jp + hi * 64 + q * 16 + 2 * lo);               // rows 2q, 2q+1 of the +j brick
+      fjm[q] = DIAG & 2 ? d2{0.125 * q, 1.0} : *(gc2)(p_jm + hi * 64 + (8 - R) * 8 + q * 16 + 2 * lo); // rows 8-R+2q, 8-R+2q+1 of the -j brick, plane k = hi
+      fjp[q] = DIAG & 2 ? d2{0.375 * q, 2.0} : *(gc2)(p_jp + hi * 64 + q * 16 + 2 * lo);               // rows 2q, 2q+1 of the +j brick
       fim[q] = fip[q] = d2{0.0, 0.0};
     }
     // i-faces (only without a sibling): the R halo columns of a (k, j) row are R x 8 contiguous bytes.  R = 2: lane (k, j) takes
@@ -219,6 +220,18 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
   } else if (stencil_id == BRK_MPI13) {
     const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
     hipLaunchKernelGGL((k_star_wg<kStarMpi13, 8, 4>), dim3(wgs), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+#ifdef BRK_DIAG // diagnostic build only (make EXTRA_HIPFLAGS=-DBRK_DIAG): these variants compute WRONG results on purpose
+  } else if (variant >= 7 && variant <= 9) { // timing experiments: 7 = no k-face loads, 8 = no j-face loads, 9 = neither (wrong results)
+    const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
+    if (variant == 7) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 1>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+    else if (variant == 8) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 2>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+    else hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 3>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+  } else if (variant >= 10 && variant <= 12) { // 10 = k-faces read from the brick itself, 11 = j-faces, 12 = both (wrong results)
+    const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
+    if (variant == 10) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 4>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+    else if (variant == 11) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 8>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+    else hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 12>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+#endif
   } else if (variant != 2) {
     const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
     hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);

@@ -105,6 +105,34 @@ __global__ __launch_bounds__(256) void k_stream2_range(const double *in, double 
 #pragma unroll
   for (int k = 0; k < 8; ++k) out[(size_t)b * step + k * 64 + lane] = v[k] * 1.0001;
 }
+// the same with non-temporal stores (what the stencil kernels use) / non-temporal loads as well
+template <int NTL>
+__global__ __launch_bounds__(256) void k_stream2_range_nt(const double *in, double *out, size_t step, uint32_t first, uint32_t n) {
+  uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= n) return;
+  uint32_t b = first + w;
+  int lane = threadIdx.x & 63;
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = NTL ? __builtin_nontemporal_load(&in[(size_t)b * step + k * 64 + lane]) : in[(size_t)b * step + k * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k] * 1.0001, &out[(size_t)b * step + k * 64 + lane]);
+}
+// XCD-aware brick order as in the stencil kernels (workgroup -> XCD slab), 8 waves per workgroup, non-temporal stores
+template <int NW, int XCD>
+__global__ __launch_bounds__(64 * NW) void k_stream2_xcd_nt(const double *in, double *out, size_t step, uint32_t first, uint32_t n) {
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = XCD ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+  uint32_t w = wg * NW + (threadIdx.x >> 6);
+  if (w >= n) return;
+  uint32_t b = first + w;
+  int lane = threadIdx.x & 63;
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = in[(size_t)b * step + k * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k] * 1.0001, &out[(size_t)b * step + k * 64 + lane]);
+}
 // persistent waves: each wave walks bricks w, w+W, ... with the next brick's loads in flight while storing
 __global__ __launch_bounds__(256) void k_stream2_persist(const double *in, double *out, size_t step, uint32_t first, uint32_t n) {
   const uint32_t W = gridDim.x * 4;
@@ -250,8 +278,10 @@ int main(int argc, char **argv) {
   CK(hipEventCreate(&e1));
   if (stream && ids_d) {
     const char *names[] = {"stream2(ids)", "stream4(ids)", "copy_lin float4 2048 blocks", "copy_lin float4 8192 blocks",
-                           "stream2_range", "stream2_persist 2048 blocks", "stream2_persist 4096 blocks"};
-    for (int which = 0; which < 7; ++which) {
+                           "stream2_range", "stream2_persist 2048 blocks", "stream2_persist 4096 blocks",
+                           "stream2_range nt stores", "stream2_range nt loads+stores", "stream2 xcd order 8 waves nt stores", "stream2 xcd order 4 waves nt stores",
+                           "stream2 natural order 8 waves nt stores", "stream2 xcd order 2 waves nt stores"};
+    for (int which = 0; which < 13; ++which) {
       auto go = [&]() {
         if (which == 0) k_stream2<<<(nlist + 3) / 4, 256>>>(st_in, st_out, step, ids_d, nlist);
         else if (which == 1) k_stream4<<<(nlist + 3) / 4, 256>>>(st_in, st_out, step, ids_d, nlist);
@@ -259,7 +289,13 @@ int main(int argc, char **argv) {
         else if (which == 3) k_copy_lin<<<8192, 256>>>((const uint4 *)st_in, (uint4 *)st_ref, (size_t)nlist * 512 / 2);
         else if (which == 4) k_stream2_range<<<(nlist + 3) / 4, 256>>>(st_in, st_out, step, 0, nlist);
         else if (which == 5) k_stream2_persist<<<2048, 256>>>(st_in, st_out, step, 0, nlist);
-        else k_stream2_persist<<<4096, 256>>>(st_in, st_out, step, 0, nlist);
+        else if (which == 6) k_stream2_persist<<<4096, 256>>>(st_in, st_out, step, 0, nlist);
+        else if (which == 7) k_stream2_range_nt<0><<<(nlist + 3) / 4, 256>>>(st_in, st_out, step, 0, nlist);
+        else if (which == 8) k_stream2_range_nt<1><<<(nlist + 3) / 4, 256>>>(st_in, st_out, step, 0, nlist);
+        else if (which == 9) k_stream2_xcd_nt<8, 1><<<(((nlist + 7) / 8 + 7) / 8) * 8, 512>>>(st_in, st_out, step, 0, nlist);
+        else if (which == 10) k_stream2_xcd_nt<4, 1><<<(((nlist + 3) / 4 + 7) / 8) * 8, 256>>>(st_in, st_out, step, 0, nlist);
+        else if (which == 11) k_stream2_xcd_nt<8, 0><<<(((nlist + 7) / 8 + 7) / 8) * 8, 512>>>(st_in, st_out, step, 0, nlist);
+        else k_stream2_xcd_nt<2, 1><<<(((nlist + 1) / 2 + 7) / 8) * 8, 128>>>(st_in, st_out, step, 0, nlist);
       };
       for (int w = 0; w < 3; ++w) go();
       CK(hipEventRecord(e0));

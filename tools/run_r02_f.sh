@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 2 evidence run (after the output-side 125-pt kernel): default bench line, kernel-trace stats of the same command, PMC passes (traffic per kernel)
+set -o pipefail
+mkdir -p gpurun_out/r02f
+timeout -k 10 600 python bench.py > gpurun_out/r02f/bench_default.json 2> gpurun_out/r02f/bench_default.err; rc=$?
+if [ $rc -ne 0 ]; then tail -5 gpurun_out/r02f/bench_default.err; exit 1; fi
+python3 -c "
+import json; d=json.loads([l for l in open('gpurun_out/r02f/bench_default.json') if l.startswith('{')][-1])
+print('headline', round(d['value'],1), 'frac', round(d['roofline']['frac'],4), 'steady', round(d['steady_state']['value'],1))
+for k,v in d['config3'].items():
+    if isinstance(v,dict): print(' ',k, round(v['kernel_ms'],4),'ms frac',round(v['roofline']['frac'],3),'err',v.get('max_abs_err_vs_oracle'))
+print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])"
+bash tools/run_gpu_checks.sh prof > gpurun_out/r02f/prof.log 2>&1; tail -12 gpurun_out/r02f/prof.log
+cp $(ls -t $(find gpurun_out/prof_kt -name "*kernel_stats.csv") | head -1) gpurun_out/r02f/kernel_stats.csv
+bash tools/prof_pmc.sh r02f > gpurun_out/r02f/pmc.log 2>&1; tail -40 gpurun_out/r02f/pmc.log
+cp gpurun_out/pmc_r02f/summary.txt gpurun_out/r02f/pmc_summary.txt; cp gpurun_out/pmc_r02f/traffic.json gpurun_out/r02f/pmc_traffic_all.json
