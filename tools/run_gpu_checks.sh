@@ -21,7 +21,7 @@ if [ "$what" = all ] || [ "$what" = bench ]; then
 fi
 if [ "$what" = all ] || [ "$what" = prof ]; then
   export TMPDIR=/tmp
-  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-weak-reference --steady-seconds 0 --windows 1 > gpurun_out/prof_kt.log 2>&1; rc=$?
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_kt.log 2>&1; rc=$?
   tail -3 gpurun_out/prof_kt.log
   if killed $rc; then echo "prof killed"; exit 1; fi
   rm -rf gpurun_out/prof_kt.prev; ls -t $(find gpurun_out/prof_kt -name "*kernel_stats.csv") | head -1 | xargs cat | head -20   # newest run only
