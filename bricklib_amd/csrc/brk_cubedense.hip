@@ -80,12 +80,17 @@ struct DX {
     const int ei = ii < R ? R - ii : (ii >= R + 8 ? ii - R - 7 : 0);
     return ek + ej + ei <= 2;
   }
+  // The full radius-2 cube gathers PAIRS of cells: its halo is two columns wide and the edge blocks are rows of eight, so every
+  // wanted cell has its i-neighbour (ii ^ 1 counted from the tile's column 0 = ii with R even) wanted too -- 16 bytes per lane,
+  // half the gather instructions, and the two cells of a 16-byte segment are no longer requested by different lanes.
+  static constexpr bool PAIR = KIND == kCube125;
   static constexpr int count(int side) {
     int n = 0;
     for (int kk = 0; kk < T; ++kk)
       for (int jj = 0; jj < T; ++jj)
         for (int ii = 0; ii < T; ++ii) {
           const int di = ii < R ? -1 : (ii >= R + 8 ? 1 : 0);
+          if (PAIR && (ii & 1)) continue;
           if (wanted(kk, jj, ii) && (di < 0 ? 1 : (di > 0 ? 2 : 0)) == side) ++n;
         }
     return n;
@@ -118,6 +123,7 @@ constexpr DenseExtra<KIND> make_dense_extra() {
           const int dj = jj < R ? -1 : (jj >= R + 8 ? 1 : 0);
           const int di = ii < R ? -1 : (ii >= R + 8 ? 1 : 0);
           if (!X::wanted(kk, jj, ii)) continue;
+          if (X::PAIR && (ii & 1)) continue; // the odd cell travels with its even neighbour
           if ((di < 0 ? 1 : (di > 0 ? 2 : 0)) != side) continue;
           const int sk = (kk - R + 8) % 8, sj = (jj - R + 8) % 8, si = (ii - R + 8) % 8;
           const int col = di < 0 ? 8 - R + ii : (di > 0 ? ii - R - 8 : ii - R);
@@ -192,6 +198,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   bool link_l = false, link_r = false, brk_l = false;
   double own[8], fkm[R], fkp[R], fjm[R], fjp[R], fim[R], fip[R];
   double xv[X::EXTRA_ITERS];
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  d2 xv2[X::EXTRA_ITERS];
+  // R = 2: the two halo rows (columns) of a j- (i-) face are 16 contiguous bytes per lane -- ONE instruction per face, every
+  // 128-byte line requested once (two 8-byte instructions ask for the same lines twice; the second request finds the miss of
+  // the first still pending and the L1 stalls on that, see brk_starwg.hip)
+  typedef const __attribute__((address_space(1))) d2 *gc2;
+  constexpr bool W16 = R == 2;
+  // the output-side 125-point form reads everything from LDS (no register copy of the brick's own column): the brick and its
+  // k-faces are moved in 16-byte lanes too -- lane l of instruction q takes elements 2(l%32), +1 of plane 2q + l/32
+  constexpr bool LD16 = KIND == kCube125 && PIPE == 5;
+  d2 own2[4], km2 = {0.0, 0.0}, kp2 = {0.0, 0.0};
+  const int l5 = lane & 31, lp = lane >> 5;
+  d2 jm2 = {0.0, 0.0}, jp2 = {0.0, 0.0}, im2 = {0.0, 0.0}, ip2 = {0.0, 0.0};
   if (active) {
     const uint32_t b_prev = w > 0 ? __builtin_amdgcn_readfirstlane(id_of(slot - 1)) : BRK_LIST_SKIP;
     const uint32_t b_next = (w + 1 < NW && slot + 1 < n) ? __builtin_amdgcn_readfirstlane(id_of(slot + 1)) : BRK_LIST_SKIP;
@@ -209,7 +228,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     __builtin_amdgcn_sched_barrier(0);
     const gcptr self = sbase(in + (size_t)b * step);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) own[k] = self[k * 64 + lane];
+    for (int k = 0; k < 8; ++k)
+      if (!LD16) own[k] = self[k * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (LD16) own2[q] = *(gc2)(self + q * 128 + 2 * lane);
     link_l = b_prev != BRK_LIST_SKIP && linked(prow, arow, lane);
     link_r = b_next != BRK_LIST_SKIP && linked(arow, nrow, lane);
     brk_l = b_prev != BRK_LIST_SKIP && !link_l; // two active neighbours that cannot share
@@ -229,25 +252,43 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     const gcptr p_jp = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 1, 0)) * step);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      fkm[r] = p_km[(8 - R + r) * 64 + lane];
-      fkp[r] = p_kp[r * 64 + lane];
-      fjm[r] = p_jm[hi * 64 + (8 - R + r) * 8 + lo];
-      fjp[r] = p_jp[hi * 64 + r * 8 + lo];
-      fim[r] = fip[r] = 0.0;
+      fkm[r] = fkp[r] = 0.0;
+      if (!LD16) {
+        fkm[r] = p_km[(8 - R + r) * 64 + lane];
+        fkp[r] = p_kp[r * 64 + lane];
+      }
+      fjm[r] = fjp[r] = fim[r] = fip[r] = 0.0;
+      if (!W16) {
+        fjm[r] = p_jm[hi * 64 + (8 - R + r) * 8 + lo];
+        fjp[r] = p_jp[hi * 64 + r * 8 + lo];
+      }
+    }
+    if (LD16) {
+      km2 = *(gc2)(p_km + 6 * 64 + 2 * lane);
+      kp2 = *(gc2)(p_kp + 2 * lane);
+    }
+    if (W16) { // lane (k = hi, chunk lo): rows 6, 7 / 0, 1 of plane k are 128 contiguous bytes
+      jm2 = *(gc2)(p_jm + hi * 64 + 48 + 2 * lo);
+      jp2 = *(gc2)(p_jp + hi * 64 + 2 * lo);
     }
     if (!link_l) {
       const gcptr p_im = sbase(in + (size_t)n_im * step);
+      if (W16) im2 = *(gc2)(p_im + hi * 64 + lo * 8 + 6); // lane (k = hi, j = lo): columns 6, 7 of its row
 #pragma unroll
-      for (int r = 0; r < R; ++r) fim[r] = p_im[hi * 64 + lo * 8 + (8 - R + r)];
+      for (int r = 0; r < R; ++r)
+        if (!W16) fim[r] = p_im[hi * 64 + lo * 8 + (8 - R + r)];
     }
     if (!link_r) {
       const gcptr p_ip = sbase(in + (size_t)n_ip * step);
+      if (W16) ip2 = *(gc2)(p_ip + hi * 64 + lo * 8);
 #pragma unroll
-      for (int r = 0; r < R; ++r) fip[r] = p_ip[hi * 64 + lo * 8 + r];
+      for (int r = 0; r < R; ++r)
+        if (!W16) fip[r] = p_ip[hi * 64 + lo * 8 + r];
     }
     auto gather = [&](int t) {
       const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((xd[t] >> 16) & 31u) << 2), (int)arow);
-      xv[t] = xd[t] != 0xFFFFFFFFu ? in[(size_t)nb * step + ((xd[t] >> 21) & 511u)] : 0.0;
+      if (X::PAIR) xv2[t] = xd[t] != 0xFFFFFFFFu ? *(const d2 *)(in + (size_t)nb * step + ((xd[t] >> 21) & 511u)) : d2{0.0, 0.0};
+      else xv[t] = xd[t] != 0xFFFFFFFFu ? in[(size_t)nb * step + ((xd[t] >> 21) & 511u)] : 0.0;
     };
 #pragma unroll
     for (int t = 0; t < X::IT0; ++t) gather(t);
@@ -279,34 +320,60 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     const bool mine = active && my_phase == ph;
     if (mine) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) tile[TL::at(k + R, hi + R, lo)] = own[k];
+      for (int k = 0; k < 8; ++k)
+        if (!LD16) tile[TL::at(k + R, hi + R, lo)] = own[k];
+      if (LD16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(d2 *)&tile[TL::at(2 * q + lp + R, (l5 >> 2) + R, 2 * (l5 & 3))] = own2[q];
+        *(d2 *)&tile[TL::at(lp, (l5 >> 2) + R, 2 * (l5 & 3))] = km2;
+        *(d2 *)&tile[TL::at(R + 8 + lp, (l5 >> 2) + R, 2 * (l5 & 3))] = kp2;
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        if (TL::has_plane(r)) tile[TL::at(r, hi + R, lo)] = fkm[r];
-        if (TL::has_plane(R + 8 + r)) tile[TL::at(R + 8 + r, hi + R, lo)] = fkp[r];
-        tile[TL::at(hi + R, r, lo)] = fjm[r];
-        tile[TL::at(hi + R, R + 8 + r, lo)] = fjp[r];
+        if (!LD16 && TL::has_plane(r)) tile[TL::at(r, hi + R, lo)] = fkm[r];
+        if (!LD16 && TL::has_plane(R + 8 + r)) tile[TL::at(R + 8 + r, hi + R, lo)] = fkp[r];
+        if (!W16) {
+          tile[TL::at(hi + R, r, lo)] = fjm[r];
+          tile[TL::at(hi + R, R + 8 + r, lo)] = fjp[r];
+        }
+      }
+      if (W16) { // rows 0, 1 (R+8, R+9) of plane k are 16 contiguous doubles of the tile
+        *(d2 *)&tile[TL::at(hi + R, 0, 0) + 2 * lo] = jm2;
+        *(d2 *)&tile[TL::at(hi + R, R + 8, 0) + 2 * lo] = jp2;
       }
       if (!link_l) {
+        if (W16) *(d2 *)&left[TL::at(hi + R, lo + R, 8 - R)] = im2;
 #pragma unroll
-        for (int r = 0; r < R; ++r) left[TL::at(hi + R, lo + R, 8 - R + r)] = fim[r];
+        for (int r = 0; r < R; ++r)
+          if (!W16) left[TL::at(hi + R, lo + R, 8 - R + r)] = fim[r];
       }
       if (!link_r) {
+        if (W16) *(d2 *)&right[TL::at(hi + R, lo + R, 0)] = ip2;
 #pragma unroll
-        for (int r = 0; r < R; ++r) right[TL::at(hi + R, lo + R, r)] = fip[r];
+        for (int r = 0; r < R; ++r)
+          if (!W16) right[TL::at(hi + R, lo + R, r)] = fip[r];
       }
 #pragma unroll
       for (int t = 0; t < X::IT0; ++t)
-        if (xd[t] != 0xFFFFFFFFu) tile[xd[t] & 0xFFFFu] = xv[t];
+        if (xd[t] != 0xFFFFFFFFu) {
+          if (X::PAIR) *(d2 *)&tile[xd[t] & 0xFFFFu] = xv2[t];
+          else tile[xd[t] & 0xFFFFu] = xv[t];
+        }
       if (!link_l) {
 #pragma unroll
         for (int t = X::IT0; t < X::IT0 + X::ITS; ++t)
-          if (xd[t] != 0xFFFFFFFFu) left[xd[t] & 0xFFFFu] = xv[t];
+          if (xd[t] != 0xFFFFFFFFu) {
+            if (X::PAIR) *(d2 *)&left[xd[t] & 0xFFFFu] = xv2[t];
+            else left[xd[t] & 0xFFFFu] = xv[t];
+          }
       }
       if (!link_r) {
 #pragma unroll
         for (int t = X::IT0 + X::ITS; t < X::EXTRA_ITERS; ++t)
-          if (xd[t] != 0xFFFFFFFFu) right[xd[t] & 0xFFFFu] = xv[t];
+          if (xd[t] != 0xFFFFFFFFu) {
+            if (X::PAIR) *(d2 *)&right[xd[t] & 0xFFFFu] = xv2[t];
+            else right[xd[t] & 0xFFFFu] = xv[t];
+          }
       }
     }
     STAMP(t4); // staged

@@ -212,6 +212,8 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   if (!adj || !in || !out) return brk_fail(BRK_EINVAL, "null device pointer");
   if (in == out) return brk_fail(BRK_EINVAL, "in and out must be different fields");
   if (step < 512) return brk_fail(BRK_EINVAL, "step_elems %zu < 512", step);
+  // the kernels move halo rows and columns in 16-byte lanes
+  if (((uintptr_t)in | (uintptr_t)out) % 16 || step % 2) return brk_fail(BRK_EINVAL, "brick fields must be 16-byte aligned (in %p, out %p, step_elems %zu)", (const void *)in, (void *)out, step);
   if (n == 0) return BRK_OK;
   const int var = g_variant[id].load(std::memory_order_relaxed);
   Coeffs cf;
@@ -415,6 +417,7 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
     if (lo[a] + cnt[a] > tot[a]) return brk_fail(BRK_EINVAL, "box exceeds the grid on axis %d", a);
   if ((uint64_t)base + (uint64_t)tot[0] * tot[1] * tot[2] > 0xFFFFFFFFull) return brk_fail(BRK_EINVAL, "brick ids overflow 32 bits");
   if (!adj || !in || !out || in == out || step < 512) return brk_fail(BRK_EINVAL, "bad device pointers / step");
+  if (((uintptr_t)in | (uintptr_t)out) % 16 || step % 2) return brk_fail(BRK_EINVAL, "brick fields must be 16-byte aligned");
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
   if ((uint64_t)cnt[0] * cnt[1] * cnt[2] == 0) return BRK_OK;
   Coeffs cf;

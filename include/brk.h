@@ -72,7 +72,9 @@ int brk_stencil_iters(int stencil_id);
  * Replaces the body of `brick(...)` launched over a grid of bricks: d3pt7_brick_trans
  * (stencils/3axis.hip.cpp:32-41,165-171), brick_kernel (weak/main.cu:35-43,277-282).
  * in/out may be two fields of one interleaved storage (single/: out_dev = in_dev+512, step_elems = 1024,
- * stencils/3axis.cpp:25-28) or two storages (step_elems = 512, weak/main.cpp:76-77). */
+ * stencils/3axis.cpp:25-28) or two storages (step_elems = 512, weak/main.cpp:76-77).  Both fields must be 16-byte aligned
+ * and step_elems even (BrickStorage allocations are 2048-byte aligned, include/brick.h:68-75 of the reference): the kernels
+ * move halo rows in 16-byte lanes; anything else is refused with BRK_EINVAL. */
 int brk_stencil_apply_range(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
                             size_t step_elems, uint32_t brick_begin, uint32_t brick_end, const double *coeff_host,
                             brk_stream s);

@@ -831,6 +831,8 @@ def test_entry_point_edge_cases(oracle, dev):
         lambda: lib.brk_stencil_apply_range(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(st.dat), 512, 1, 2, None, None),     # in == out
         lambda: lib.brk_stencil_apply_range(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 256, 1, 2, None, None),     # step < 512
         lambda: lib.brk_stencil_apply_range(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, 5, 2, None, None),     # reversed
+        lambda: lib.brk_stencil_apply_range(bl.BRK_MPI7, _ptr(info.adj), C.c_void_p(st.dat.data_ptr() + 8), _ptr(so.dat), 512, 1, 2, None, None),  # field not 16-byte aligned
+        lambda: lib.brk_stencil_apply_range(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 513, 1, 2, None, None),      # odd step
         lambda: lib.brk_stencil_apply_range(bl.BRK_7PT_COEFF, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, 1, 2, None, None),  # no coefficients
         lambda: lib.brk_stencil_apply_range(42, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, 1, 2, None, None),               # unknown stencil
         lambda: lib.brk_stencil_apply_list(bl.BRK_MPI7, _ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, None, 3, None, None),     # null list
