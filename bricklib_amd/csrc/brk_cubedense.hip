@@ -460,6 +460,10 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
     hipLaunchKernelGGL((k_cube_dense<kCube125, 8, 2>), dim3(wgs8), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 11) { // row-pipelined plane loop with 5 rows in flight (spills)
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 4>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+#ifdef BRK_DIAG // occupancy experiment: the default kernel with unused dynamic LDS -> 2 groups (8 waves) / 1 group (4 waves) per CU
+  } else if (variant == 13 || variant == 14) {
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 5>), dim3(wgs4), dim3(256), variant == 13 ? 26000 : 60000, st, adj, in, out, step, ids, first, n, cf);
+#endif
   } else if (variant == 10) { // input-side accumulation, row-pipelined plane loop, 3 rows of LDS reads in flight
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 3>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 9) {

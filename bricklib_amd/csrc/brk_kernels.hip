@@ -232,7 +232,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = var;
-    if (v == 0 || (v >= 5 && v <= 12)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st);
+    if (v == 0 || (v >= 5 && v <= 14)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st);
     if ((id == BRK_27PT_COEFF && v == 2) || (id == BRK_MPI125 && (v == 2 || v == 4 || v == 8)))
       return launch_cube_wg(id, id == BRK_MPI125 ? v : 8, adj, in, out, step, ids, first, n, cf, st);
   }
