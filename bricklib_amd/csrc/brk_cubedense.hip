@@ -207,8 +207,12 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   constexpr bool W16 = R == 2;
   // the output-side 125-point form reads everything from LDS (no register copy of the brick's own column): the brick and its
   // k-faces are moved in 16-byte lanes too -- lane l of instruction q takes elements 2(l%32), +1 of plane 2q + l/32
-  constexpr bool LD16 = KIND == kCube125 && PIPE == 5;
-  d2 own2[4], km2 = {0.0, 0.0}, kp2 = {0.0, 0.0};
+  constexpr bool KF16 = KIND == kCube125 && PIPE == 5; // both planes of a k-face go to LDS: one full-wave instruction per side
+  constexpr bool LD16 = KF16 || KIND == kCube27; // (the diamond at 128 VGPRs spills with the 16-byte staging registers: 0.53 vs 0.43 ms)
+  // 27-point: ONE plane per side goes to LDS (plane 7 below -> level R-1, plane 0 above -> level R+8): both sides in one
+  // instruction, half a wave each
+  constexpr bool KF16H = LD16 && !KF16;
+  d2 own2[4], km2 = {0.0, 0.0}, kp2 = {0.0, 0.0}, kh2 = {0.0, 0.0}, jh2 = {0.0, 0.0};
   const int l5 = lane & 31, lp = lane >> 5;
   d2 jm2 = {0.0, 0.0}, jp2 = {0.0, 0.0}, im2 = {0.0, 0.0}, ip2 = {0.0, 0.0};
   if (active) {
@@ -253,20 +257,20 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       fkm[r] = fkp[r] = 0.0;
-      if (!LD16) {
-        fkm[r] = p_km[(8 - R + r) * 64 + lane];
-        fkp[r] = p_kp[r * 64 + lane];
-      }
+      if (!LD16 || (KF16H && !TL::has_plane(r))) fkm[r] = p_km[(8 - R + r) * 64 + lane];
+      if (!LD16 || (KF16H && !TL::has_plane(R + 8 + r))) fkp[r] = p_kp[r * 64 + lane];
       fjm[r] = fjp[r] = fim[r] = fip[r] = 0.0;
-      if (!W16) {
+      if (!W16 && !LD16) {
         fjm[r] = p_jm[hi * 64 + (8 - R + r) * 8 + lo];
         fjp[r] = p_jp[hi * 64 + r * 8 + lo];
       }
     }
-    if (LD16) {
+    if (KF16) {
       km2 = *(gc2)(p_km + 6 * 64 + 2 * lane);
       kp2 = *(gc2)(p_kp + 2 * lane);
     }
+    if (KF16H) kh2 = *(gc2)((lp ? p_kp : p_km + 7 * 64) + 2 * l5);
+    if (LD16 && R == 1) jh2 = *(gc2)((lp ? p_jp : p_jm + 56) + (l5 >> 2) * 64 + 2 * (l5 & 3)); // row 7 below / row 0 above of plane l5/4
     if (W16) { // lane (k = hi, chunk lo): rows 6, 7 / 0, 1 of plane k are 128 contiguous bytes
       jm2 = *(gc2)(p_jm + hi * 64 + 48 + 2 * lo);
       jp2 = *(gc2)(p_jp + hi * 64 + 2 * lo);
@@ -325,14 +329,19 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
       if (LD16) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) *(d2 *)&tile[TL::at(2 * q + lp + R, (l5 >> 2) + R, 2 * (l5 & 3))] = own2[q];
-        *(d2 *)&tile[TL::at(lp, (l5 >> 2) + R, 2 * (l5 & 3))] = km2;
-        *(d2 *)&tile[TL::at(R + 8 + lp, (l5 >> 2) + R, 2 * (l5 & 3))] = kp2;
+        if (KF16) {
+          *(d2 *)&tile[TL::at(lp, (l5 >> 2) + R, 2 * (l5 & 3))] = km2;
+          *(d2 *)&tile[TL::at(R + 8 + lp, (l5 >> 2) + R, 2 * (l5 & 3))] = kp2;
+        } else {
+          *(d2 *)&tile[TL::at(lp ? R + 8 : R - 1, (l5 >> 2) + R, 2 * (l5 & 3))] = kh2;
+          if (R == 1) *(d2 *)&tile[TL::at((l5 >> 2) + R, lp ? R + 8 : 0, 2 * (l5 & 3))] = jh2;
+        }
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         if (!LD16 && TL::has_plane(r)) tile[TL::at(r, hi + R, lo)] = fkm[r];
         if (!LD16 && TL::has_plane(R + 8 + r)) tile[TL::at(R + 8 + r, hi + R, lo)] = fkp[r];
-        if (!W16) {
+        if (!W16 && !LD16) {
           tile[TL::at(hi + R, r, lo)] = fjm[r];
           tile[TL::at(hi + R, R + 8 + r, lo)] = fjp[r];
         }
