@@ -211,9 +211,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
 
 int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
-  // Smaller workgroups = more of them resident and less lockstep between the load and the compute phase.  Measured at
-  // 512^3: 13-pt 4 waves (32 KiB LDS, 5 groups = 20 waves/CU) 0.402 ms vs 8 waves (64 KiB, 16 waves/CU) 0.431 ms;
-  // 25-pt (12 KiB of LDS per wave, 12 waves/CU either way) 2 waves 0.532 ms vs 4 waves 0.545 ms.  Variant 2 = the larger group.
+  // Smaller workgroups = more of them resident and less lockstep between the load and the compute phase; larger ones share more
+  // i-faces.  Measured at 512^3: 13-pt 4 waves (32 KiB LDS, 5 groups = 20 waves/CU) 0.392 ms vs 8 waves (64 KiB, 16 waves/CU)
+  // 0.408 ms; 25-pt (12 KiB of LDS per wave, 12 waves/CU either way) 4 waves 0.502 ms vs 2 waves 0.507 ms -- since every line of a
+  // face is requested once the 25-pt i-faces are the dearer part (before that: 2 waves 0.532 vs 4 waves 0.545).  Variant 2 = the
+  // other group size.
   if (stencil_id == BRK_MPI13 && variant != 2) {
     const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
     hipLaunchKernelGGL((k_star_wg<kStarMpi13, 4, 5>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
@@ -232,7 +234,7 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
     else if (variant == 11) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 8>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
     else hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 12>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
 #endif
-  } else if (variant != 2) {
+  } else if (variant == 2) {
     const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
     hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
   } else {
