@@ -15,7 +15,11 @@
 // runs of a group are 2-coloured and processed in two phases; regular lists never take the second phase.
 // Links are exact: a pair shares only if all 9 adjacency entries on the common side agree both ways, so any BrickInfo
 // is handled (irregular ones at fallback speed).
-// LDS per workgroup: (NW+1) tiles = 57.6 KiB (27-pt, NW 8, 2 groups/CU) / 46 KiB (125-pt, NW 4, 3 groups/CU).
+// LDS per workgroup: (NW+1) tiles = 31.3 KiB (27-pt, NW 4, 5 groups/CU) / 45 KiB + 6 KiB of output-side shift slots (125-pt,
+// NW 4, 3 groups/CU) / 37.5 KiB (fused double 7-point sweep, NW 4, 4 groups/CU).
+// Fetch path (round 2): everything that only goes to LDS moves in 16-byte lanes -- the brick (4 instructions), the k-, j- and
+// i-faces (one instruction per face for R = 2, both sides of a face in one instruction for R = 1), the radius-2 cube's edge and
+// corner cells as pairs -- so that every 128-byte line is requested by one instruction of the wave.
 #include "brk_device.h"
 
 namespace brk {
