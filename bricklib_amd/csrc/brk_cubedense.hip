@@ -47,6 +47,19 @@ extern "C" int brk_debug_stamps(unsigned long long out[8], int reset) {
   }
   return 0;
 }
+// the same totals by position of the wave in its group of four (slot & 3): are the group's end waves the late ones?
+extern "C" int brk_debug_stamps_by_wave(unsigned long long out[4][8]) {
+  static unsigned long long *host = new unsigned long long[(size_t)kStampSlots * 6];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * kStampSlots * 6) != hipSuccess) return -1;
+  for (int w = 0; w < 4; ++w)
+    for (int q = 0; q < 8; ++q) out[w][q] = 0;
+  for (size_t sl = 0; sl < kStampSlots; ++sl)
+    if (host[sl * 6 + 1]) {
+      for (int q = 0; q < 6; ++q) out[sl & 3][q] += host[sl * 6 + q];
+      ++out[sl & 3][7];
+    }
+  return 0;
+}
 #else
 #define STAMP(var)
 #endif

@@ -333,6 +333,17 @@ int main(int argc, char **argv) {
       // totals of k_cube_dense (in-kernel s_memtime stamps, one row per list slot)
       typedef int (*stamp_fn)(unsigned long long *, int);
       static stamp_fn stamps = (stamp_fn)dlsym(RTLD_DEFAULT, "brk_debug_stamps");
+      typedef int (*stampw_fn)(unsigned long long (*)[8]);
+      static stampw_fn stamps_w = (stampw_fn)dlsym(RTLD_DEFAULT, "brk_debug_stamps_by_wave");
+      if (stamps_w) {
+        unsigned long long tw[4][8];
+        if (stamps_w(tw) == 0)
+          for (int w4 = 0; w4 < 4; ++w4)
+            if (tw[w4][7])
+              printf("   wave %d of its group: ids %.0f | adjacency %.0f | issue %.0f | loads back %.0f | stage+barriers %.0f | compute+store %.0f\n", w4,
+                     (double)tw[w4][0] / tw[w4][7], (double)tw[w4][1] / tw[w4][7], (double)tw[w4][2] / tw[w4][7], (double)tw[w4][3] / tw[w4][7],
+                     (double)tw[w4][4] / tw[w4][7], (double)tw[w4][5] / tw[w4][7]);
+      }
       if (stamps) {
         unsigned long long t[8];
         if (stamps(t, 1) == 0 && t[7]) {
