@@ -161,6 +161,24 @@ def test_cpp_weak_driver_exchange_views():
     assert "GStencil/s" in out
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("args", [("64", "16", "3"), ("64", "16", "1"), ("64", "32", "8"), ("128", "32", "5")])
+def test_cpp_strong_driver_validates(args):
+    """examples/strong_hip.cpp: the reference's strong driver shape in C++ over the C ABI -- Z-Morton ownership
+    (brk_strong_partition / brk_strong_neighbor), block-diagonal adjacency, same-rank ghost runs as device links, one packed
+    message per peer (brk_xplan_build_tables -> brk_exchange_begin / loopback / end), ST_ITER 13-point sweeps over all
+    subdomains of a rank in one launch; the driver's own `-v` check (global periodic array swept on the CPU) must say Validated."""
+    exe = os.path.join(ROOT, "examples", "strong_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "strong_hip"])
+    r = subprocess.run([exe, *args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out
+    assert "Validated" in out and "INVALID" not in out and "GStencil/s" in out, out
+    assert out.count("rank ") >= int(args[2]), out
+
+
 @pytest.mark.parametrize("dims", [(32, 24, 16), (16, 16, 16), (64, 40, 48)])
 def test_mpi_side_headers(tmp_path, dims):
     """include/bitset.h, zmort.h and brick-mpi.h (BitSet, ZMORT, BrickDecomp<3,8,8,8>, skin3d_good, allneighbors,
