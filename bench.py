@@ -242,11 +242,50 @@ def run_single(args, bl, dev):
         else:
             bl.apply_stencil(sid, bIn, bOut, ids=ids_dev, coeff=coeff, stream=stream)
 
+    cells = float(N) ** 3
+    extra = {}
+    if args.steady_seconds > 0:
+        # >= 2 s of back-to-back launches (clocks and memory at their sustained state).  Runs BEFORE the headline
+        # windows: with the driver's --steps 20 a window is 8 ms, and measured straight after process start it sits on the clock
+        # ramp; after this phase the W warm-up steps + K timed steps below see the device in the state a sweep loop runs in.
+        for _ in range(max(W, 3)):
+            step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(20):
+            step()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        est_ms = e0.elapsed_time(e1) / 20          # calibration only: how many launches make args.steady_seconds
+        per = max(K, 100)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        n_l = 0
+        while True:
+            for _ in range(per):
+                step()
+            n_l += per
+            if n_l * est_ms * 1e-3 >= args.steady_seconds:
+                break
+        e1.record(stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        extra["steady_state"] = {"seconds": dt, "launches": n_l, "kernel_ms": e0.elapsed_time(e1) / n_l,
+                                 "value": cells * n_l / dt / 1e9, "unit": "GStencil/s",
+                                 "roofline_frac": BYTES_PER_UPDATE * cells / (e0.elapsed_time(e1) / n_l * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # the reference's GPU protocol hiptime_func (stencils/stencils.hip.h:13-31): 1 warm-up + 100 launches between two events
+        from bricklib_amd.timing import hiptime_func
+        sec = hiptime_func(step, stream)
+        extra["hiptime_func"] = {"seconds_per_launch": sec, "value": cells / sec / 1e9, "unit": "GStencil/s",
+                                 "protocol": "hiptime_func (stencils/stencils.hip.h:13-31): warm-up + 100 launches between events"}
     for _ in range(W):
         step()
     torch.cuda.synchronize()
     # The timed region is exactly K steps between two synchronisations; it is repeated `--windows` times back to back and the
-    # MEDIAN window is the headline (a single window of 20 launches is 8 ms: clock ramp and box noise move it by a few %).
+    # MEDIAN window is the headline (a single window of 20 launches is 8 ms: box noise moves it by a few %).
     # Every window is reported.
     wins = []
     for _ in range(max(1, args.windows)):
@@ -261,37 +300,12 @@ def run_single(args, bl, dev):
         wins.append((time.perf_counter() - t0, e0.elapsed_time(e1) / K))
     order = sorted(range(len(wins)), key=lambda q: wins[q][0])
     wall, kern_ms = wins[order[len(order) // 2]]
-    cells = float(N) ** 3
     res = {"workload": f"single-{name}-{N}" + (f"-variant{args.variant}" if args.variant else ""), "layout": args.layout, "form": args.form, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
            "kernel": "%s over %d bricks" % ("k_s7_wg<8 waves>" if name in ("7pt", "mpi7pt") else ("k_star_wg" if name in ("mpi13pt", "mpi25pt") else "k_cube_dense"), ids.size)}
-    extra = {"timing": {"protocol": "median of %d windows of %d launches, each between two device synchronisations" % (len(wins), K),
-                        "window_ms_per_step": [w / K * 1e3 for w, _ in wins], "window_kernel_ms": [k for _, k in wins]}}
-    if args.steady_seconds > 0:
-        # >= 2 s of back-to-back launches (clocks and memory at their sustained state)
-        per = max(K, 100)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        e0.record(stream)
-        n_l = 0
-        while True:
-            for _ in range(per):
-                step()
-            n_l += per
-            if n_l * kern_ms * 1e-3 >= args.steady_seconds:
-                break
-        e1.record(stream)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        extra["steady_state"] = {"seconds": dt, "launches": n_l, "kernel_ms": e0.elapsed_time(e1) / n_l,
-                                 "value": cells * n_l / dt / 1e9, "unit": "GStencil/s",
-                                 "roofline_frac": BYTES_PER_UPDATE * cells / (e0.elapsed_time(e1) / n_l * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        # the reference's GPU protocol hiptime_func (stencils/stencils.hip.h:13-31): 1 warm-up + 100 launches between two events
-        from bricklib_amd.timing import hiptime_func
-        sec = hiptime_func(step, stream)
-        extra["hiptime_func"] = {"seconds_per_launch": sec, "value": cells / sec / 1e9, "unit": "GStencil/s",
-                                 "protocol": "hiptime_func (stencils/stencils.hip.h:13-31): warm-up + 100 launches between events"}
+    extra["timing"] = {"protocol": "%s%d warm-up steps, then the median of %d windows of %d launches, each between two device synchronisations"
+                                   % ("the steady-state phase first; " if args.steady_seconds > 0 else "", W, len(wins), K),
+                       "window_ms_per_step": [w / K * 1e3 for w, _ in wins], "window_kernel_ms": [k for _, k in wins]}
     O = None
     try:
         from oracle.oracle import Oracle
