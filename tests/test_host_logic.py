@@ -219,6 +219,62 @@ def test_exchange_plans_host_side(oracle):
     assert ok.bytes_remote == 4096 and ok.buffer_bytes(0, 1, SP_SEND) == 4096 and ok.my_rank == 2
 
 
+@pytest.mark.parametrize("dom", [(16, 16, 16), (32, 16, 24), (24, 40, 16)])
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 6, 8, 12])
+def test_exchange_plans_route_the_right_bytes(oracle, dom, world):
+    """The plans of ALL ranks of a periodic grid, interpreted in one address space (numpy; no GPU, no processes): begin copies,
+    messages matched in order per (stage, sender, receiver), end copies -- stage by stage, for the packed, direct and shift
+    forms -- must leave every rank's storage exactly as the oracle's run-by-run exchange (brick-mpi.h:466-495) does.  This is the
+    N > 1 data path of bench.py minus the wire: the same tables drive brk_exchange_begin / _transport / _end on the GPUs."""
+    from bricklib_amd.decomp import SP_RECV, SP_SEND, SP_STORAGE, XPlan, populate, rank_to_coo
+    cart = bl.dims_create(world)
+    od = oracle.decomp(dom)
+    nbytes = od.nbricks * 4096
+    init = [(np.arange(od.nbricks * 512, dtype=np.float64) + r * 1e9) for r in range(world)]
+    maps = [oracle.populate_rank_map(cart, rank_to_coo(r, cart)) for r in range(world)]
+    want = [a.copy() for a in init]
+    oracle.exchange(od, want, maps, 512)
+    for mode in ("packed", "direct", "shift"):
+        plans = []
+        for r in range(world):
+            d = bl.BrickDecomp(dom)
+            populate(d, cart, rank_to_coo(r, cart))
+            plans.append(XPlan.from_decomp(d, r, mode, 512))
+        st = [a.copy().view(np.uint8) for a in init]
+        assert all(s_.size == nbytes for s_ in st)
+        for stage in range(plans[0].nstages):
+            buf = {}     # (rank, space, peer) -> bytearray-like
+
+            def space(r, sp, peer, need):
+                if sp == SP_STORAGE:
+                    return st[r]
+                b = buf.setdefault((r, sp, peer), np.zeros(plans[r].buffer_bytes(stage, peer, sp), dtype=np.uint8))
+                assert need <= b.size, (mode, r, sp, peer, need, b.size)
+                return b
+
+            def run_copies(phase):
+                for r, p in enumerate(plans):
+                    for c in p.copies:
+                        if c["stage"] == stage and c["phase"] == phase:
+                            src = space(r, c["src_space"], c["src_peer"], c["src_off"] + c["bytes"])
+                            dst = space(r, c["dst_space"], c["dst_peer"], c["dst_off"] + c["bytes"])
+                            dst[c["dst_off"]:c["dst_off"] + c["bytes"]] = src[c["src_off"]:c["src_off"] + c["bytes"]].copy()
+
+            run_copies(0)
+            for r, p in enumerate(plans):
+                for peer in range(world):
+                    sends = [m for m in p.msgs if m["stage"] == stage and m["is_send"] and m["peer"] == peer]
+                    recvs = [m for m in plans[peer].msgs if m["stage"] == stage and not m["is_send"] and m["peer"] == r]
+                    assert [m["bytes"] for m in sends] == [m["bytes"] for m in recvs], (mode, stage, r, peer)
+                    for a, b in zip(sends, recvs):
+                        src = space(r, a["space"], peer, a["off"] + a["bytes"])
+                        dst = space(peer, b["space"], r, b["off"] + b["bytes"])
+                        dst[b["off"]:b["off"] + b["bytes"]] = src[a["off"]:a["off"] + a["bytes"]].copy()
+            run_copies(1)
+        for r in range(world):
+            assert (st[r].view(np.float64) == want[r]).all(), (mode, r)
+
+
 def test_exchange_plan_covers_ghost_once():
     d = bl.BrickDecomp((32, 32, 32))
     covered = np.zeros(d.nbricks, dtype=np.int32)
