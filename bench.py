@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: GStencil/s (lattice updates/s) of the 7-pt fp64 brick sweep, 512^3 per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts its N ranks itself, as a child torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N = 1  workload "single-7pt-512": the reference's single/hip d3pt7 `Trans` launch (stencils/3axis.hip.cpp:165-171):
@@ -68,6 +68,7 @@ def parse():
                     help="weak workload on ONE GPU: send the self-neighbour runs through a 1-rank RCCL communicator (ncclSend/ncclRecv "
                          "to self inside libbrk.so) instead of device links -- exercises the whole pack -> RCCL -> unpack path, on the "
                          "exchange stream of the chosen schedule, where only one GPU is available")
+    ap.add_argument("--test-fail-comm", action="store_true", help=argparse.SUPPRESS)   # tests: creating the C-ABI communicator fails
     ap.add_argument("--watchdog-seconds", type=float, default=900.0,
                     help="N > 1: a rank that has not finished after this long prints where it was and exits with status 3")
     ap.add_argument("--no-scaling-base", action="store_true", help="N > 1: skip the 1-GPU run of the same workload on rank 0")
@@ -177,31 +178,63 @@ def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, 
 
 
 def make_comm(args, world, dev):
-    """The RCCL communicator of the C-ABI transport (bricklib_amd.decomp.Comm), or None for the torch transport.
+    """(communicator of the C-ABI transport or None, transport name, fallback reason or None).
     rank 0's ncclUniqueId travels over the torch.distributed group; after that torch is not in the data path.  With
     --transport auto a failure to create it on ANY rank (librccl not loadable, ncclCommInitRank error) makes EVERY rank fall back
-    to the torch transport: the ranks agree through an all-reduce before any data moves."""
-    if world == 1 or args.backend != "nccl" or args.transport == "torch":
-        return None
-    import torch.distributed as dist
+    to the torch transport: Comm.bootstrap_all_or_none cannot diverge before its all-reduce, so the decision is collective.
+    One GPU with --self-via-comm: a 1-rank communicator; its torch fallback is a 1-rank nccl process group (main())."""
+    via_self = world == 1 and args.self_via_comm
+    if not via_self and (world == 1 or args.backend != "nccl"):
+        return None, ("gloo-staged" if world > 1 else "device links"), None
+    if args.transport == "torch":
+        return None, "torch", None
     from bricklib_amd.decomp import Comm
-    comm, err = None, None
-    try:
-        comm = Comm.bootstrap()
-    except Exception as e:           # BrkError from libbrk.so, or a failed broadcast
-        if args.transport == "abi":
-            raise
-        err = e
-    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 1:
-        return comm
+    if args.test_fail_comm:          # test hook: the communicator cannot be created (what a missing librccl looks like)
+        def _no_id():
+            raise RuntimeError("--test-fail-comm: brk_comm_unique_id made to fail")
+        Comm.unique_id = staticmethod(_no_id)
+    if via_self:
+        try:
+            return Comm.init_rank(Comm.unique_id(), 0, 1), "abi: RCCL send/recv to self", None
+        except Exception as e:
+            comm, why = None, repr(e)
+    else:
+        comm, why = Comm.bootstrap_all_or_none(device=dev)
+        if comm is not None:
+            return comm, "abi", None
     if args.transport == "abi":
-        raise RuntimeError("the C-ABI RCCL communicator could not be created on every rank")
-    sys.stderr.write(f"bench.py: C-ABI communicator unavailable on some rank ({err!r} here): all ranks use the torch transport\n")
-    if comm is not None:
-        comm.destroy()
-    return None
+        raise RuntimeError(f"--transport abi: the C-ABI RCCL communicator could not be created on every rank ({why})")
+    sys.stderr.write(f"bench.py: C-ABI communicator unavailable ({why}): all ranks use the torch transport\n")
+    return None, "torch", why
+
+
+def exchange_self_check(d, st, ex, rank, world, dev, label):
+    """One exchange on recognisable data BEFORE anything is timed (reference rule, include/brick-mpi.h:476-491: ghost run i <- skin
+    run i of the rank behind ghost[i].neighbor): every rank writes rank * 2^20 + brick id into its surface bricks and -1 into its
+    ghost bricks, exchanges once and checks every ghost run against the ids its peer must have sent.  Returns None, or a text naming
+    the first wrong run.  A mis-routed or mis-ordered run becomes a non-zero exit, not a silent drift."""
+    s0, s1, s2 = d.sep_pos
+    v = st.dat.view(-1, st.step)
+    v[s0:s1] = (torch.arange(s0, s1, device=dev, dtype=torch.float64) + float(rank << 20))[:, None]
+    v[s1:s2] = -1.0
+    torch.cuda.synchronize()
+    ex.exchange(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    want = np.empty(s2 - s1, dtype=np.float64)
+    for g, k in zip(d.ghost, d.skin):
+        src = d.rank_map[g["neighbor"]]
+        want[g["pos"] - s1:g["pos"] - s1 + g["len"]] = np.arange(k["pos"], k["pos"] + g["len"], dtype=np.float64) + float(src << 20)
+    bad = (v[s1:s2] != torch.from_numpy(want).to(dev)[:, None]).any(dim=1).cpu().numpy()
+    if not bad.any():
+        return None
+    b = int(np.argmax(bad)) + s1
+    for q, g in enumerate(d.ghost):
+        if g["pos"] <= b < g["pos"] + g["len"]:
+            got = float(v[b, 0].item())
+            return (f"exchange self-check ({label}) FAILED on rank {rank}: ghost run {q} (neighbor set {g['neighbor']:#x}, from rank "
+                    f"{d.rank_map[g['neighbor']]}), brick {b}: holds {got:.0f} = rank {int(got) >> 20} brick {int(got) & 0xFFFFF}, "
+                    f"expected rank {d.rank_map[g['neighbor']]} brick {d.skin[q]['pos'] + b - g['pos']}; {int(bad.sum())} ghost bricks wrong")
+    return f"exchange self-check ({label}) FAILED on rank {rank}: brick {b} outside every ghost run"
 
 
 def run_single(args, bl, dev):
@@ -351,14 +384,56 @@ def run_weak(args, bl, dev, rank, world):
     bl.populate(d, cart, rank_to_coo(rank, cart))
     info = d.getBrickInfo(dev)
     stA, stB = info.allocate(512, dev), info.allocate(512, dev)
-    stA.dat.uniform_(0.0, 1.0)
     A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
-    comm = make_comm(args, world, dev)
-    if comm is None and world == 1 and args.self_via_comm:
-        from bricklib_amd.decomp import Comm
-        comm = Comm.init_rank(Comm.unique_id(), 0, 1)
-    ex = Exchanger(d, stA, rank, mode=args.exchange, staged=args.backend == "gloo" and world > 1, comm=comm,
-                   self_via_comm=world == 1 and args.self_via_comm)
+    comm, transport, fallback_reason = make_comm(args, world, dev)
+
+    def make_exchanger(c):
+        return Exchanger(d, stA, rank, mode=args.exchange, staged=args.backend == "gloo" and world > 1, comm=c,
+                         self_via_comm=world == 1 and args.self_via_comm)
+
+    ex = make_exchanger(comm)
+    # ---- before anything is timed: which GPUs, and does one exchange put every peer's bricks where they belong? ---------------
+    ranks_seen = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "device": torch.cuda.current_device(), "name": props.name,
+              "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+              "uuid": str(getattr(props, "uuid", ""))}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
+        distinct = len({(x["pci"], x["uuid"]) for x in ranks_seen})
+        if args.backend == "nccl" and distinct != world:      # every rank sees the same list: every rank leaves
+            raise SystemExit(f"bench.py: {world} ranks on {distinct} distinct GPUs ({[x['pci'] for x in ranks_seen]}): one rank per GPU is required under RCCL")
+
+    def checked_exchange(label):
+        wd_ = _watchdog(min(args.watchdog_seconds, 240.0), rank, f"the exchange self-check ({label}): a send/recv that never completes")
+        try:
+            err = exchange_self_check(d, stA, ex, rank, world, dev, label)
+        except Exception as e:
+            err = f"exchange self-check ({label}) raised on rank {rank}: {e!r}"
+        wd_.cancel()
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return err, int(flag.item()) != 0
+
+    err, any_bad = checked_exchange(transport)
+    if any_bad and transport == "abi" and args.transport == "auto":
+        # the C-ABI communicator exists but its exchange failed somewhere: every rank (the all-reduce above) moves to the torch transport
+        if err:
+            sys.stderr.write(err + "\n")
+        fallback_reason = err or "the self-check failed on another rank"
+        torch.cuda.synchronize()
+        comm.destroy()
+        comm, transport = None, "torch"
+        ex = make_exchanger(None)
+        err, any_bad = checked_exchange(transport)
+    if any_bad:
+        if err:
+            sys.stderr.write(err + "\n")
+        raise SystemExit(4)
+    self_check = {"passed": True, "transport": transport, "ghost_runs": len(d.ghost), "messages": ex.messages}
+    stA.dat.uniform_(0.0, 1.0)
     if args.emulate_exchange_ms > 0:
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # calibrate torch.cuda._sleep
         torch.cuda._sleep(1000000)
@@ -501,22 +576,15 @@ def run_weak(args, bl, dev, rank, world):
     res = {"workload": f"weak-{name[:-3] if upd == 2 else name}-{N}", "conservation_rel_drift": drift, "updates_per_pass": upd, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,   # per pass: one read + one write per cell
            "kernel": "%s passes over brick lists of BrickDecomp(%d^3): %d passes (%d sweeps) + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S * upd, S),
-           "cart": cart, "overlap": overlap, "exchange": args.exchange, "transport": ("abi" if comm is not None else ("gloo-staged" if args.backend == "gloo" else "torch")) if world > 1 else ("abi: RCCL send/recv to self" if comm is not None else "device links"),
+           "cart": cart, "overlap": overlap, "exchange": args.exchange, "transport": transport, "transport_fallback_reason": fallback_reason, "exchange_self_check": self_check,
            "schedule": schedule, "deep_depth": deep_depth if schedule == "deep" else None, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
            "remote_bytes_per_rank": ex.bytes_remote, "messages_per_exchange": ex.messages,
            "per_peer_send_bytes": {str(k): v for k, v in sorted(per_peer.items())},
            "per_peer_GBps_exchange_alone": {str(k): v / (exchange_ms * 1e-3) / 1e9 for k, v in sorted(per_peer.items())} if exchange_ms > 0 else None}
     extra = {}
     if world > 1:
-        # which GPUs the ranks really ran on (N distinct devices under RCCL), gathered over the process group
-        props = torch.cuda.get_device_properties(dev)
-        me = {"rank": rank, "device": torch.cuda.current_device(), "name": props.name,
-              "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
-              "uuid": str(getattr(props, "uuid", ""))}
-        seen = [None] * world
-        dist.all_gather_object(seen, me)
-        res["ranks_seen"] = seen
-        res["distinct_gpus"] = len({(x["pci"], x["uuid"]) for x in seen})
+        res["ranks_seen"] = ranks_seen            # gathered (and checked: N distinct GPUs under RCCL) before the timed region
+        res["distinct_gpus"] = len({(x["pci"], x["uuid"]) for x in ranks_seen})
         if not args.no_scaling_base:
             # the like-for-like base of a scaling curve: the SAME workload (same stencil, fusion, sweeps per exchange) on one
             # GPU with a self-periodic 1x1x1 decomposition, measured here on rank 0's GPU outside the timed region
@@ -562,8 +630,9 @@ def run_strong(args, bl, dev, rank, world):
     comm = None
     if args.backend == "gloo":
         transport = staged_transport
-    elif world > 1 and (comm := make_comm(args, world, dev)) is not None:
+    elif world > 1 and (cm := make_comm(args, world, dev))[0] is not None:
         from bricklib_amd.strong import rccl_transport
+        comm = cm[0]
         transport = rccl_transport(comm)
     else:
         transport = nccl_transport
@@ -618,14 +687,14 @@ def run_strong(args, bl, dev, rank, world):
     return res, {}
 
 
-def _watchdog(seconds, rank):
+def _watchdog(seconds, rank, what="the run"):
     """A rank that hangs (a collective that never completes, a peer that died) must not sit there forever: after `seconds`
     the process reports and exits with status 3.  os._exit from a timer thread: no re-exec, no retry, nothing touches the GPU."""
     import faulthandler
     import threading
 
     def fire():
-        sys.stderr.write(f"bench.py: rank {rank} did not finish within {seconds:.0f} s -- giving up (exit 3)\n")
+        sys.stderr.write(f"bench.py: rank {rank} did not finish {what} within {seconds:.0f} s -- giving up (exit 3)\n")
         faulthandler.dump_traceback(file=sys.stderr)
         sys.stderr.flush()
         os._exit(3)
@@ -636,13 +705,43 @@ def _watchdog(seconds, rank):
     return t
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD process (torch.distributed.run,
+    one rank per GPU -- the `mpirun -np N weak/cuda` of the reference, weak/main.cu:46-60,246-287), let it write to our stdout /
+    stderr and leave with its return code.  This parent never touches the GPU (torch.cuda.device_count() does not initialise it
+    on this image) and nothing is re-exec'd."""
+    import subprocess
+    if args.backend == "nccl":
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} over RCCL needs {args.gpus} visible GPUs, this host shows {have} "
+                             f"(--backend gloo rehearses the multi-rank control flow on fewer)\n")
+            raise SystemExit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")         # what torchrun would set anyway, without its warning
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                   # does not return
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
     import bricklib_amd as bl
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path)"
     if args.backend == "gloo":
@@ -662,6 +761,13 @@ def main():
             dist.init_process_group("gloo", timeout=tmo)
         else:
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+    elif args.self_via_comm and args.transport != "abi":
+        # one GPU, self-neighbour runs through a communicator: the torch transport (and --transport auto's fallback to it) needs a
+        # 1-rank RCCL process group
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
     workload = args.workload or ("single" if world == 1 else "weak")
     if workload == "single":
         res, extra = run_single(args, bl, dev)
@@ -676,7 +782,9 @@ def main():
                 w, _ = run_weak(a2, bl, dev, 0, 1)
                 extra["weak_workload_on_this_gpu"] = {"value": w["cells_per_step"] * w["K"] / w["wall"] / 1e9, "unit": "GStencil/s",
                                                       "ms_per_step": w["wall"] / w["K"] * 1e3, "workload": w["workload"],
-                                                      "updates_per_pass": w["updates_per_pass"], "schedule": w["schedule"]}
+                                                      "updates_per_pass": w["updates_per_pass"], "schedule": w["schedule"],
+                                                      "conservation_rel_drift": w["conservation_rel_drift"],
+                                                      "exchange_self_check": w["exchange_self_check"]}
             except Exception as e:
                 extra["weak_workload_on_this_gpu"] = {"error": repr(e)}
     elif workload == "strong":
@@ -692,7 +800,7 @@ def main():
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
                        **{k: res[k] for k in ("layout", "form", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
-                                             "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift", "transport", "messages_per_exchange",
+                                             "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift", "transport", "transport_fallback_reason", "exchange_self_check", "messages_per_exchange",
                                              "per_peer_send_bytes", "per_peer_GBps_exchange_alone", "distinct_gpus", "ranks_seen") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],
@@ -710,8 +818,8 @@ def main():
         out.update(extra)
         out.setdefault("cpu_baseline", None)
         print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
     if wd is not None:
         wd.cancel()

@@ -217,11 +217,38 @@ class Comm:
 
     @classmethod
     def bootstrap(cls, group=None):
+        """Rank 0 ALWAYS takes part in the broadcast: what travels is (id, error text), so a rank 0 that cannot produce an id
+        (librccl not loadable) does not leave the others waiting in the broadcast -- every rank raises after it."""
         import torch.distributed as dist
         rank, size = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None, None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as e:
+                box[1] = repr(e)
         dist.broadcast_object_list(box, src=0, group=group)
+        if box[0] is None:
+            raise RuntimeError(f"rank 0 could not create an RCCL unique id: {box[1]}")
         return cls.init_rank(box[0], rank, size)
+
+    @classmethod
+    def bootstrap_all_or_none(cls, group=None, device=None):
+        """(comm, None) on every rank, or (None, reason) on every rank: the ranks agree through a MIN all-reduce that every rank
+        reaches -- bootstrap() cannot diverge before it -- so a later fallback to another transport is a collective decision."""
+        import torch.distributed as dist
+        comm, err = None, None
+        try:
+            comm = cls.bootstrap(group)
+        except Exception as e:           # BrkError from libbrk.so (ncclCommInitRank), or rank 0's id error relayed above
+            err = repr(e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=device or "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            return comm, None
+        if comm is not None:
+            comm.destroy()
+        return None, err or "the communicator could not be created on another rank"
 
     def destroy(self):
         if self._h:

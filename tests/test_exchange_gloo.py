@@ -71,3 +71,61 @@ def test_exchange_two_ranks_gloo(oracle, world, mode):
     for r in range(world):
         assert (got[r][0] == storages[r]).all(), r
         assert got[r][1] > 0        # some runs really went over the wire
+
+
+def _bootstrap_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from bricklib_amd.decomp import Comm
+        calls = {"init": 0}
+
+        def no_id():
+            raise RuntimeError("librccl could not be loaded (test)")
+
+        def no_init(uid, r, n):
+            calls["init"] += 1
+            raise RuntimeError("ncclCommInitRank must not be reached")
+
+        Comm.unique_id = staticmethod(no_id)          # what rank 0 sees when RCCL is missing; the other ranks never call it
+        Comm.init_rank = classmethod(lambda cls, uid, r, n: no_init(uid, r, n))
+        comm, why = Comm.bootstrap_all_or_none()
+        # the ranks are still in step: a collective right behind the decision completes on all of them
+        t = torch.tensor([rank + 1])
+        dist.all_reduce(t)
+        q.put((rank, comm is None, why, int(t.item()), calls["init"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_comm_bootstrap_failure_is_collective():
+    """rank 0 failing to create the RCCL id must not leave the other ranks inside the broadcast (mismatched collectives,
+    hang until the watchdog).  Every rank gets (None, reason) from bootstrap_all_or_none and the group is still usable."""
+    world = 3
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bootstrap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(g[0] for g in got) == [0, 1, 2]
+    for rank, none, why, total, inits in got:
+        assert none and "librccl could not be loaded (test)" in why and total == 6 and inits == 0
+
+
+def test_bench_gpus_n_without_gpus_fails_fast():
+    """`python bench.py --gpus 2` on a host without two GPUs: one clear line and a non-zero status before any rank is started
+    (the parent never initialises the GPU runtime)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300,
+                       env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this host has two GPUs")
+    assert r.returncode == 2 and b"needs 2 visible GPUs" in r.stderr and r.stdout.strip() == b""
