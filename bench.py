@@ -143,6 +143,36 @@ def cpu_baseline(O, sid, info, st, step, ids, coeff, n_cells, seconds):
                       f"(OpenMP, {cores} threads), {dt:.1f} s"}
 
 
+def cpu_baseline_reference(n_cells_axis, seconds):
+    """The reference's OWN CPU code on this host: its `_TILEFOR` loop nest (stencils/stencils.h:30-38) around its `ST_CPU`
+    7-point arithmetic (stencils/fake.h:345-349) -- array layout, compiled in place into oracle/_ref/libbrickref.so
+    (oracle/ref_cpu_sweep.cpp) -- under the reference's `time_func`.  A stated baseline beside the port, never the target.
+    One call updates STRIDEG^3 = (N + 16)^3 points (the reference sweeps its ghost zone too); the rate counts those."""
+    import ctypes as C
+    from bricklib_amd.timing import time_func
+    path = os.path.join(ROOT, "oracle", "_ref", "libbrickref.so")
+    if n_cells_axis != 512 or not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    if not hasattr(L, "ref_cpu_sweep_mpi7"):
+        return None
+    L.ref_cpu_sweep_stride.restype = L.ref_cpu_sweep_points.restype = C.c_long
+    cores = usable_cores()
+    L.ref_cpu_sweep_threads(cores)
+    stride, points = int(L.ref_cpu_sweep_stride()), int(L.ref_cpu_sweep_points())
+    a = np.random.default_rng(3).random(stride ** 3)
+    b = np.zeros_like(a)
+    fn = L.ref_cpu_sweep_mpi7
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    pa, pb = a.ctypes.data, b.ctypes.data
+    per_call, calls, dt = time_func(lambda: fn(pa, pb), seconds)
+    return {"value": points / per_call / 1e9, "unit": "GStencil/s", "cores": cores, "kind": "reference ST_CPU, array layout",
+            "useful_value": float(n_cells_axis) ** 3 / per_call / 1e9,
+            "protocol": "time_func (stencils/stencils.h:40-53), TOT_TIME = %.0f s" % seconds,
+            "sample": f"{calls} calls of the reference's _TILEFOR + ST_CPU (7-point, MPI_ALPHA/MPI_BETA) over a {stride}^3 array: "
+                      f"{points} points per call incl. its ghost zone ({n_cells_axis}^3 useful = useful_value), OpenMP {cores} threads, {dt:.1f} s"}
+
+
 def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, launches=100, nsample=512, warm_ms=150.0):
     """One of the other stencils of BASELINE configs 2-3 on the SAME 512^3 grid through the same box entry point, outside
     the timed headline: kernel time from HIP events on the launch stream, roofline fraction, sampled oracle check."""
@@ -366,6 +396,11 @@ def run_single(args, bl, dev):
             extra["cpu_baseline"] = cpu_baseline(O, sid, info, st, step_e, ids, coeff, cells, args.cpu_seconds)
         except Exception as e:
             extra["oracle_error"] = repr(e)
+    if not args.no_cpu_baseline:
+        try:        # second, clearly labelled leg: the reference's own array code (only built for 512^3)
+            extra["cpu_baseline_reference"] = cpu_baseline_reference(N, min(args.cpu_seconds, 8.0))
+        except Exception as e:
+            extra["cpu_baseline_reference"] = {"error": repr(e)}
     return res, extra
 
 

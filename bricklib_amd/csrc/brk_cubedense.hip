@@ -472,32 +472,32 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8, wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
   if ((stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2) && variant == 2) { // plane loop without read-ahead
-    hipLaunchKernelGGL((k_cube_dense<kDiamond25, 4, 4, 0>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kDiamond25, 4, 4, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else if (stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2) {
-    hipLaunchKernelGGL((k_cube_dense<kDiamond25, 4, 4>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kDiamond25, 4, 4>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else if (stencil_id == BRK_27PT_COEFF) {
     if (variant == 5)
-      hipLaunchKernelGGL((k_cube_dense<kCube27, 8, 4>), dim3(wgs8), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+      hipLaunchKernelGGL((k_cube_dense<kCube27, 8, 4>), dim3(wgs8), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
     else
-      hipLaunchKernelGGL((k_cube_dense<kCube27, 4, 5>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+      hipLaunchKernelGGL((k_cube_dense<kCube27, 4, 5>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 6) {
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 2>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 2>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 7) {
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 8, 2>), dim3(wgs8), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 8, 2>), dim3(wgs8), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 11) { // row-pipelined plane loop with 5 rows in flight (spills)
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 4>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 4>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
 #ifdef BRK_DIAG // occupancy experiment: the default kernel with unused dynamic LDS -> 2 groups (8 waves) / 1 group (4 waves) per CU
   } else if (variant == 13 || variant == 14) {
     hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 5>), dim3(wgs4), dim3(256), variant == 13 ? 26000 : 60000, st, adj, in, out, step, ids, first, n, cf);
 #endif
   } else if (variant == 10) { // input-side accumulation, row-pipelined plane loop, 3 rows of LDS reads in flight
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 3>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 3>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 9) {
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 0>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant == 5) { // fully unrolled plane loop, reads of a plane in one burst (the round-1 default)
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 2>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 2>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else { // default (0, 12): output-side j-shift -- 60 + 40 LDS reads per lane, the shift through a wave-private slot
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 5>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 5>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;

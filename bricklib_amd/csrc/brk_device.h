@@ -10,6 +10,9 @@
 
 namespace brk {
 
+// development knob (tools/kbench -L): unused dynamic LDS added to every stencil launch -> fewer workgroups resident per CU
+extern size_t g_pad_lds;
+
 constexpr int kWavesPerWG = 4;
 constexpr int kWG = 64 * kWavesPerWG;
 

@@ -8,7 +8,18 @@
 // already loaded RCCL (same soname) is the one that answers.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// building without the RCCL development header: the few types of its C API this file names (values as in nccl.h); the
+// library itself is still only looked for at run time, and brk_comm_* / the transport report BRK_ECOMM when it is absent
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+  char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+#endif
 
 #include <algorithm>
 #include <cstring>

@@ -278,6 +278,11 @@ int make_geom(const long dimlist[3], const long padding[3], const long ghost[3],
 
 } // namespace
 
+namespace brk {
+size_t g_pad_lds = 0;
+}
+extern "C" void brk_debug_pad_lds(size_t bytes) { brk::g_pad_lds = bytes; }
+
 extern "C" int brk_set_variant(int id, int v) {
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
   g_variant[id] = v;
@@ -290,8 +295,8 @@ extern "C" int brk_set_variant(int id, int v) {
 // Lifetime rules (brk.h promises thread safety for distinct streams and devices):
 //   * the cache mutex is held from the lookup until the launch that reads the list has been enqueued and an event has been
 //     recorded behind it on the launch stream -- another thread cannot replace the entry in between;
-//   * a replaced list is not freed in place: it waits for its last reader's event (that stream only, no device-wide
-//     synchronisation) and is released on the device that owns it.
+//   * a replaced list is not freed in place and nothing waits under the mutex: it moves to a retired list and is released by a
+//     later call once hipEventQuery says its last reader has finished (no device-wide synchronisation, no hipSetDevice).
 struct BoxList {
   uint32_t key[11];
   uint32_t *dev;
@@ -304,6 +309,26 @@ constexpr int kBoxCache = 16;
 BoxList g_box[kBoxCache];
 uint64_t g_box_clock = 0;
 std::mutex g_box_mutex;
+struct RetiredList {
+  uint32_t *dev;
+  hipEvent_t last_use;
+};
+std::vector<RetiredList> g_box_retired;
+
+// caller holds g_box_mutex: free the retired lists whose last reader has finished; never blocks
+void reap_retired_locked() {
+  size_t keep = 0;
+  for (size_t q = 0; q < g_box_retired.size(); ++q) {
+    if (hipEventQuery(g_box_retired[q].last_use) == hipSuccess) {
+      (void)hipFree(g_box_retired[q].dev);
+      (void)hipEventDestroy(g_box_retired[q].last_use);
+    } else {
+      (void)hipGetLastError(); // hipErrorNotReady is not an error of this call
+      g_box_retired[keep++] = g_box_retired[q];
+    }
+  }
+  g_box_retired.resize(keep);
+}
 
 // caller holds g_box_mutex
 int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], BoxList **entry) {
@@ -341,14 +366,9 @@ int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], 
   std::vector<uint32_t> host(per * 8, BRK_LIST_SKIP);
   for (uint32_t x = 0; x < 8; ++x) std::copy(part[x].begin(), part[x].end(), host.begin() + x * per);
   BoxList &e = g_box[victim];
-  if (e.dev) {
-    // retire the replaced list on its own device once its last reader has finished
-    if (e.device != device) HIP_TRY(hipSetDevice(e.device));
-    hipError_t r = hipEventSynchronize(e.last_use);
-    if (r == hipSuccess) r = hipFree(e.dev);
-    if (r == hipSuccess) r = hipEventDestroy(e.last_use);
-    if (e.device != device) HIP_TRY(hipSetDevice(device));
-    HIP_TRY(r);
+  reap_retired_locked();
+  if (e.dev) { // the replaced list may still be read by a launch in flight (any device): it is released by a later call
+    g_box_retired.push_back({e.dev, e.last_use});
     e.dev = nullptr;
   }
   HIP_TRY(hipMalloc(&e.dev, host.size() * sizeof(uint32_t)));

@@ -344,7 +344,7 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
     const uint32_t nw = variant == 5 ? 8 : 4;
     const uint32_t wgs = (((n + nw - 1) / nw + 7) / 8) * 8;
 #define BRK_LAUNCH_WG(M, W, I) \
-  hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), 0, st, adj, in, out, step, ids, first, n, Box{}, cf)
+  hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf)
 #define BRK_LAUNCH_WG_K(K, W)                      \
   do {                                            \
     if (ids) BRK_LAUNCH_WG(K, W, kModeList);      \
@@ -364,11 +364,11 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
   } else { // variant 2: one brick per wave, every face gathered
     const uint32_t wgs = (((n + kWavesPerWG - 1) / kWavesPerWG + 7) / 8) * 8;
     if (kind == kMpi)
-      hipLaunchKernelGGL(k_s7<kMpi>, dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf);
+      hipLaunchKernelGGL(k_s7<kMpi>, dim3(wgs), dim3(kWG), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
     else if (kind == kCond)
-      hipLaunchKernelGGL(k_s7<kCond>, dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf);
+      hipLaunchKernelGGL(k_s7<kCond>, dim3(wgs), dim3(kWG), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
     else
-      hipLaunchKernelGGL(k_s7<kCoeff>, dim3(wgs), dim3(kWG), 0, st, adj, in, out, step, ids, first, n, cf);
+      hipLaunchKernelGGL(k_s7<kCoeff>, dim3(wgs), dim3(kWG), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;
@@ -387,11 +387,11 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
   if (per_xcd == 0) return BRK_OK;
   const uint32_t n = cnt[0] * cnt[1] * cnt[2];
   if (stencil_id == BRK_MPI7)
-    hipLaunchKernelGGL((k_s7_wg<kMpi, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+    hipLaunchKernelGGL((k_s7_wg<kMpi, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
   else if (stencil_id == BRK_COND7)
-    hipLaunchKernelGGL((k_s7_wg<kCond, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+    hipLaunchKernelGGL((k_s7_wg<kCond, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
   else
-    hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), 0, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+    hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

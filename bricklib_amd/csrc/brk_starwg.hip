@@ -218,28 +218,28 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
   // other group size.
   if (stencil_id == BRK_MPI13 && variant != 2) {
     const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 4, 5>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 4, 5>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else if (stencil_id == BRK_MPI13) {
     const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 8, 4>), dim3(wgs), dim3(512), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 8, 4>), dim3(wgs), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
 #ifdef BRK_DIAG // diagnostic build only (make EXTRA_HIPFLAGS=-DBRK_DIAG): these variants compute WRONG results on purpose
   } else if (variant >= 7 && variant <= 9) { // timing experiments: 7 = no k-face loads, 8 = no j-face loads, 9 = neither (wrong results)
     const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
-    if (variant == 7) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 1>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
-    else if (variant == 8) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 2>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
-    else hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 3>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+    if (variant == 7) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 1>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    else if (variant == 8) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 2>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    else hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 3>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else if (variant >= 10 && variant <= 12) { // 10 = k-faces read from the brick itself, 11 = j-faces, 12 = both (wrong results)
     const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
-    if (variant == 10) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 4>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
-    else if (variant == 11) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 8>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
-    else hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 12>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+    if (variant == 10) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 4>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    else if (variant == 11) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 8>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    else hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 12>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
 #endif
   } else if (variant == 2) {
     const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3>), dim3(wgs), dim3(128), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   } else {
     const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 4, 3>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 4, 3>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;

@@ -11,6 +11,7 @@
 
 #include <ostream>
 #include <stdexcept>
+#include <string>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -53,7 +54,8 @@ struct ExchangeView {
 };
 typedef ExchangeView MultiStageExchangeView; // the three-stage form is the same object over a BRK_XCHG_SHIFT plan
 
-// timing accumulators the reference's drivers print (src/brick-mpi.cpp:7)
+// timing accumulators the reference's drivers print (src/brick-mpi.cpp:7); bricktime.h's time_mpi zeroes them when it sees this macro
+#define BRK_HAVE_TIMERS 1
 inline double packtime = 0, calltime = 0, waittime = 0, movetime = 0, calctime = 0;
 
 // all 3^dim subsets of {+-1..+-dim} with at most one sign per axis, in the reference's order (src/brick-mpi.cpp:9-23);
@@ -158,12 +160,24 @@ public:
     }
   }
 
+  // the communicator's idea of this rank must be the rank map's (ranks[13] = self): a communicator made from another MPI
+  // communicator than the one populate() mapped (a reordered cart vs MPI_COMM_WORLD) would send to the wrong peers silently
+  void check_comm_rank(const int ranks[27]) const {
+    if (!rccl_comm) return;
+    int r = -1;
+    if (brk_comm_rank(rccl_comm, &r, nullptr) != BRK_OK) throw std::runtime_error(brk_last_error());
+    if (r != ranks[13])
+      throw std::runtime_error("BrickDecomp: rccl_comm says rank " + std::to_string(r) + ", populate() mapped this rank as " +
+                               std::to_string(ranks[13]) + " -- make the communicator from the communicator populate() was given");
+  }
+
   // exchangeView(bStorage) of the reference (:525-585): the exchange of one DEVICE storage as an object.  mode: BRK_XCHG_PACKED
   // (one message per peer, default), BRK_XCHG_DIRECT (one per run, the reference's message pattern), BRK_XCHG_SHIFT.
   // flags: BRK_XCHG_SELF_VIA_COMM sends runs whose peer is this rank through the communicator too (single-GPU tests of the transport).
   ExchangeView exchangeView(const BrickStorage &bStorage_dev, int mode = BRK_XCHG_PACKED, unsigned flags = 0) const {
     int ranks[27];
     ranks27(ranks);
+    check_comm_rank(ranks);
     ExchangeView ev;
     ev.rccl_comm = rccl_comm;
     if (brk_xplan_build_decomp(h_, ranks, ranks[13], mode, flags, bStorage_dev.step, &ev.plan) != BRK_OK ||
@@ -182,6 +196,7 @@ public:
   void exchange_device(BrickStorage &bStorage_dev, void *stream = nullptr) {
     int ranks[27];
     ranks27(ranks);
+    check_comm_rank(ranks);
     if (brk_exchange(h_, bStorage_dev.dat.get(), bStorage_dev.step, rccl_comm, ranks, stream) != BRK_OK)
       throw std::runtime_error(brk_last_error());
   }
@@ -272,9 +287,17 @@ inline void *brkCommFromMPI(MPI_Comm comm) {
   int rank = 0, size = 1;
   MPI_Comm_rank(comm, &rank);
   MPI_Comm_size(comm, &size);
-  char id[128];
-  if (rank == 0 && brk_comm_unique_id(id) != BRK_OK) throw std::runtime_error(brk_last_error());
-  MPI_Bcast(id, 128, MPI_CHAR, 0, comm);
+  // rank 0 ALWAYS takes part in the broadcast: a status byte travels with the id, and every rank throws after it when rank 0
+  // could not make one (librccl missing) -- nobody is left waiting inside MPI_Bcast
+  char msg[129] = {0};
+  std::string why;
+  if (rank == 0 && brk_comm_unique_id(msg + 1) != BRK_OK) {
+    msg[0] = 1;
+    why = brk_last_error();
+  }
+  MPI_Bcast(msg, 129, MPI_CHAR, 0, comm);
+  if (msg[0]) throw std::runtime_error("brkCommFromMPI: rank 0 could not create an RCCL unique id" + (why.empty() ? std::string() : ": " + why));
+  const char *id = msg + 1;
   void *c = nullptr;
   if (brk_comm_init_rank(&c, size, id, rank) != BRK_OK) throw std::runtime_error(brk_last_error());
   return c;

@@ -67,8 +67,8 @@ double time_mpi(T func, int &cnt, decomp &) {
   int it = MPI_ITER;
   cnt = 0;
   func(); // warm up
-#ifdef BRK_H
-  packtime = calltime = waittime = movetime = calctime = 0; // include brick-mpi.h first: these are its accumulators
+#ifdef BRK_HAVE_TIMERS
+  packtime = calltime = waittime = movetime = calctime = 0; // brick-mpi.h (included first) defines the accumulators and this macro
 #endif
   double st = brk_time::now();
   for (int i = 0; i < MPI_ITER; ++i) func();

@@ -163,6 +163,37 @@ def test_cpp_weak_driver_exchange_views():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("flags", [(), ("-c",)])
+def test_cpp_weak_driver_one_process_per_rank_under_mpiexec(flags):
+    """examples/weak_hip_mpi.cpp: the reference's weak GPU driver as it is STARTED (weak/main.cu:46-60,246-287): a process per rank
+    under mpiexec, MPI_Cart_create + populate(cart, ...), one GPU per rank, the RCCL communicator made from the cart communicator
+    (brkCommFromMPI), ExchangeView on the device storage, time_mpi.  One rank here (one GPU per box); with -c the self-neighbour
+    runs travel through RCCL.  It must print the reference's statistics lines (weak/main.cpp:271-289) and no `result mismatch!`
+    (its own check: the GPU brick_func against MPI exchange + accessor sweeps on the host)."""
+    import shutil
+    mpiexec = shutil.which("mpiexec") or ("/opt/conda/bin/mpiexec" if os.path.exists("/opt/conda/bin/mpiexec") else None)
+    exe = os.path.join(ROOT, "examples", "weak_hip_mpi")
+    if mpiexec is None or not os.path.exists("/opt/conda/lib/libmpi.so"):
+        pytest.skip("no MPI implementation on this box")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "weak_hip_mpi"])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + env.get("LD_LIBRARY_PATH", "")   # system libstdc++ before conda's
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run([mpiexec, "-np", "1", exe, "-s", "64", "-I", "20", *flags], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240, env=env)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out
+    assert "result mismatch!" not in out, out
+    for line in ("Bri: ", "calc [", "call [", "wait [", "  | MPI size (MB): ", "perf ", " GStencil/s", "Total of 42 parts"):
+        assert line in out, (line, out)
+    msgs = int(out.split(" RCCL messages per exchange")[0].split()[-1])
+    assert msgs == (1 if flags else 0), out
+    worst = float(out.split("validation: max |gpu - host| over the subdomains = ")[1].split()[0])
+    assert worst <= 1e-12, out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("args", [("64", "16", "3"), ("64", "16", "1"), ("64", "32", "8"), ("128", "32", "5")])
 def test_cpp_strong_driver_validates(args):
     """examples/strong_hip.cpp: the reference's strong driver shape in C++ over the C ABI -- Z-Morton ownership

@@ -104,7 +104,7 @@ def test_ragged_list_lengths_and_empty(oracle, dev):
         assert np.abs(sto.dat.cpu().numpy() - want).max() <= TOL
 
 
-@pytest.mark.parametrize("name", ["mpi7pt", "mpi13pt", "mpi125pt"])
+@pytest.mark.parametrize("name", ["mpi7pt", "mpi13pt", "mpi25pt", "mpi125pt"])
 def test_range_form_decomp_order(oracle, dev, name):
     """brick ranges over BrickDecomp numbering (weak/ shape): [1,sep2) sweep incl. ghost ring reading dummy brick 0."""
     dom = (24, 16, 32)
@@ -447,7 +447,7 @@ def test_full_size_512_properties(oracle, dev, name, form):
     assert np.abs(got - want.reshape(-1, 512)[sub]).max() <= TOL
 
 
-@pytest.mark.parametrize("name", ["7pt", "mpi7pt", "mpi13pt", "27pt", "mpi125pt"])
+@pytest.mark.parametrize("name", ["7pt", "mpi7pt", "mpi13pt", "mpi25pt", "27pt", "mpi125pt"])
 @pytest.mark.parametrize("shape", [(10, 10, 10), (7, 21, 5), (66, 13, 4)])
 def test_box_form(oracle, dev, name, shape):
     """brk_stencil_apply_box: the reference launch shape (interior box of an init_grid numbering), ids derived in the
@@ -1014,3 +1014,127 @@ def test_bench_transport_auto_falls_back_to_torch():
     c2 = d2["config"]
     assert c2["transport"].startswith("abi") and c2["transport_fallback_reason"] is None and c2["exchange_self_check"]["passed"]
     assert c2["conservation_rel_drift"] <= 1e-12 and c2["messages_per_exchange"] == c["messages_per_exchange"]
+
+
+@pytest.mark.timeout(900)
+def test_weak_cycle_baseline_size_512(oracle, dev):
+    """BASELINE config 4 at its real size on one GPU: ONE periodic 1x1x1 rank of 512^3 (BrickDecomp, region-ordered ids, 287 497
+    bricks, 42 ghost runs = 104 MB per exchange), one brick_func cycle (weak/main.cpp:172-213) of the 7-point stencil as 8 sweeps
+    and as 4 fused double sweeps, under every schedule (plain / surface overlap / deep overlap) and with the exchange done by
+    device links and through the 1-rank RCCL communicator (pack -> ncclSend/ncclRecv -> unpack, C ABI).
+    Checks: (1) all schedule x transport combinations of one stencil give the same field BIT FOR BIT; (2) the periodic global
+    sum is conserved to 1e-12; (3) the whole subdomain equals the oracle's cycle -- oracle exchange, 7 sweeps over [1,sep2) and
+    one over [1,sep1) on the same bricks -- within the parity bar; (4) fused and plain cycles agree to rounding."""
+    from bricklib_amd.decomp import Comm, Exchanger
+    from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
+    N = 512
+    d = bl.BrickDecomp((N, N, N))
+    rmap = bl.populate(d, [1, 1, 1], [0, 0, 0])
+    assert d.sep_pos == [238329, 262145, 287497] and len(d.ghost) == 42
+    info = d.getBrickInfo(dev)
+    s0, s1, s2 = d.sep_pos
+    torch.manual_seed(5)
+    init = torch.rand(d.nbricks * 512, dtype=torch.float64, device=dev)
+    init[512 * s1:] = -7.0                    # ghosts: junk until exchanged
+    init[:512] = 0.0                          # brick 0: the padding brick every out-of-domain neighbour points to
+    stA, stB = info.allocate(512, dev), info.allocate(512, dev)
+    A, B = bl.Brick(info, stA, 0), bl.Brick(info, stB, 0)
+    lists = SweepLists(d, dev)
+    main, xs = torch.cuda.current_stream(), torch.cuda.Stream()
+    comm = Comm.init_rank(Comm.unique_id(), 0, 1)
+    sum0 = float(init[512:512 * s1].sum().item())
+    results = {}
+    try:
+        for name in ("mpi7pt", "mpi7pt_x2"):
+            S = bl.stencil_iters(name)
+            deep = TrapezoidLists(d, S, dev)
+            ref = None
+            for via in ("links", "rccl"):
+                ex = Exchanger(d, stA, 0, mode="packed", comm=comm if via == "rccl" else None, self_via_comm=via == "rccl")
+                assert (ex.messages >= 1) == (via == "rccl")
+                for schedule in ("plain", "surface", "deep"):
+                    stA.dat.copy_(init)
+                    stB.dat.zero_()
+                    if schedule == "deep":
+                        weak_cycle_deep(name, d, A, B, ex.exchange, deep, main=main, comm=xs)
+                    else:
+                        weak_cycle(name, d, A, B, ex.exchange, main=main, comm=xs, overlap=schedule == "surface", lists=lists, state={})
+                    torch.cuda.synchronize()
+                    got = stA.dat[512:512 * s1]
+                    drift = abs(float(got.sum().item()) - sum0) / abs(sum0)
+                    assert drift <= 1e-12, (name, via, schedule, drift)
+                    if ref is None:
+                        ref = got.clone()
+                    else:
+                        assert torch.equal(ref, got), (name, via, schedule)
+                del ex
+            results[name] = ref
+    finally:
+        torch.cuda.synchronize()
+        comm.destroy()
+    assert (results["mpi7pt"] - results["mpi7pt_x2"]).abs().max().item() <= TOL
+    # the oracle's cycle on the same bricks
+    cur = init.cpu().numpy()
+    maps = [oracle.populate_rank_map([1, 1, 1], [0, 0, 0])]
+    od = oracle.decomp((N, N, N))
+    oracle.exchange(od, [cur], maps, 512)
+    nxt = np.zeros_like(cur)
+    for sweep in range(8):
+        last = sweep == 7
+        oracle.brick_stencil(ST_MPI7, d.adj, cur, nxt, 512, n=(s1 if last else s2) - 1, first=1)
+        cur, nxt = nxt, cur
+    want = torch.from_numpy(cur[512:512 * s1]).to(dev)
+    for name in results:
+        err = (results[name] - want).abs().max().item()
+        assert err <= TOL, (name, err)
+
+
+@pytest.mark.timeout(900)
+def test_strong_cycle_baseline_shape_512_128(oracle, dev):
+    """BASELINE config 5's shape on one GPU at half the edge: global 512^3 in 64 subdomains of 128^3 (Z-Morton ids, 18^3 bricks
+    each, one launch per sweep over all of them), 13-point stencil, one exchange + ST_ITER = 4 sweeps (strong/main.cu:397-510).
+    Checks: conservation of the periodic global sum to 1e-12, and one whole subdomain plus the sampled corners of all the others
+    against the global periodic array swept by the oracle (the reference's own -v validation compares against exactly that,
+    strong/main.cpp:359-365,402-464)."""
+    from bricklib_amd.strong import StrongRank
+    dom, sub = 512, 128
+    sr = StrongRank(dom, sub, 0, 1, dev)
+    nper = dom // sub
+    assert sr.nsub == nper ** 3 and sr.peers == []
+    # the field as a global periodic array, cut into the subdomains' interiors (ghosts arrive by the exchange)
+    rng = np.random.default_rng(9)
+    g = rng.random((dom, dom, dom))
+    view = sr.storages[0].dat.view(sr.nsub, sr.nb, 512)
+    view.zero_()
+    for q in range(sr.nsub):
+        x, y, z = sr.origin(q)            # global cell coordinate (i, j, k) of subdomain slot q (Z-Morton id q)
+        blk = np.zeros((sub + 16,) * 3)
+        blk[8:-8, 8:-8, 8:-8] = g[z:z + sub, y:y + sub, x:x + sub]
+        bl.copyToBrick((sub + 16,) * 3, (0,) * 3, (0,) * 3, torch.from_numpy(blk).to(dev), sr.grid_dev, sr.sub_brick(0, q))
+    sum0 = float(view[:, 1:sr.d.sep_pos[1]].sum().item())
+    assert abs(sum0 - g.sum()) <= 1e-9 * g.sum()
+    sr.exchange(None, torch.cuda.current_stream())      # one rank: every ghost run is a device link
+    sr.sweeps("mpi13pt")
+    torch.cuda.synchronize()
+    view = sr.storages[0].dat.view(sr.nsub, sr.nb, 512)
+    drift = abs(float(view[:, 1:sr.d.sep_pos[1]].sum().item()) - sum0) / sum0
+    assert drift <= 1e-12, drift
+    # oracle: 4 sweeps of the global periodic array (wrap-padded by 8 = 4 sweeps x radius 2)
+    cur = np.pad(g, 8, mode="wrap")
+    for s in range(1, 5):
+        nxt = np.zeros_like(cur)
+        oracle.array_stencil(ST_MPI13, cur, nxt, (2 * s,) * 3, tuple(dom + 16 - 2 * s for _ in range(3)))
+        cur = nxt
+    core = cur[8:-8, 8:-8, 8:-8]
+    for q in range(sr.nsub):
+        x, y, z = sr.origin(q)
+        got = torch.zeros((sub + 16,) * 3, dtype=torch.float64, device=dev)
+        bl.copyFromBrick((sub,) * 3, (0,) * 3, (8,) * 3, got, sr.grid_dev, sr.sub_brick(0, q))
+        want = core[z:z + sub, y:y + sub, x:x + sub]
+        gg = got[8:-8, 8:-8, 8:-8]
+        if q % 9 == 0:                 # every ninth subdomain whole, of the others the 8^3 corner blocks
+            err = np.abs(gg.cpu().numpy() - want).max()
+        else:
+            err = max(np.abs(gg[a:a + 8, b:b + 8, c:c + 8].cpu().numpy() - want[a:a + 8, b:b + 8, c:c + 8]).max()
+                      for a in (0, sub - 8) for b in (0, sub - 8) for c in (0, sub - 8))
+        assert err <= TOL, (q, err)

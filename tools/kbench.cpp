@@ -173,6 +173,11 @@ int main(int argc, char **argv) {
     else if (o == "-o") order = atoi(argv[++a]); // 0 lexi; J>0: per-XCD j-slabs of 8 rows, swept in sub-blocks of J rows over all k
     else if (o == "-k") kstack = atoi(argv[++a]); // with -o: workgroup = 8 i-bricks x kstack k-levels
     else if (o == "-c") stream = true;     // also run the streaming-ceiling kernels
+    else if (o == "-L") {                  // unused dynamic LDS per launch: fewer workgroups resident per CU (occupancy experiments)
+      typedef void (*pad_fn)(size_t);
+      pad_fn pad = (pad_fn)dlsym(RTLD_DEFAULT, "brk_debug_pad_lds");
+      if (pad) pad((size_t)atol(argv[++a]));
+    }
     else if (o == "-v") {
       variants.clear();
       char *tok = strtok(argv[++a], ",");
