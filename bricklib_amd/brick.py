@@ -43,9 +43,34 @@ class BrickInfo:
             self.to(device)
 
     def to(self, device):
+        """The device copy of a table that came from the host (init_grid, BrickDecomp.getBrickInfo, movBrickInfo) belongs to this
+        object and is never written again -- the reference's BrickInfo is filled once by its builders -- so it is registered
+        with the library as immutable (brk_adjacency_register): kernels may then skip adjacency rows they can predict.  A table
+        handed in as a device tensor stays unregistered (its owner may rewrite it)."""
         if self.adj is None or self.adj.device != torch.device(device):
+            self._release()
             self.adj = _as_u32_tensor(self.adj_host, device).reshape(-1, 27)
+            if self.adj.device.type == "cuda":
+                import weakref
+                ptr, dev = self.adj.data_ptr(), self.adj.device
+                with torch.cuda.device(dev):
+                    check(lib.brk_adjacency_register(C.c_void_p(ptr), self.nbricks))
+                keep = self.adj               # the finalizer holds the tensor: the table outlives its registration
+
+                def fin(ptr=ptr, dev=dev, keep=keep):
+                    try:
+                        with torch.cuda.device(dev):
+                            lib.brk_adjacency_release(C.c_void_p(ptr))
+                    except Exception:
+                        pass
+                self._fin = weakref.finalize(self, fin)
         return self
+
+    def _release(self):
+        fin = getattr(self, "_fin", None)
+        if fin is not None:
+            fin()
+            self._fin = None
 
     def allocate(self, step, device="cuda"):
         return BrickStorage.allocate(self.nbricks, step, device)

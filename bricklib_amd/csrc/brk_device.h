@@ -12,6 +12,7 @@ namespace brk {
 
 // development knob (tools/kbench -L): unused dynamic LDS added to every stencil launch -> fewer workgroups resident per CU
 extern size_t g_pad_lds;
+extern int g_diag; // diagnostic builds (-DBRK_DIAG): which timing experiment the 7-point box kernel runs (tools/kbench -D)
 
 constexpr int kWavesPerWG = 4;
 constexpr int kWG = 64 * kWavesPerWG;
@@ -41,7 +42,8 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
                  const uint32_t *ids, uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 
 int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, double *out, size_t step, uint32_t base,
-                     const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const Coeffs &cf, hipStream_t st);
+                     const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const Coeffs &cf, hipStream_t st,
+                     const uint32_t *regmask);
 
 // 13-/25-point kernels with workgroup-shared i-halos (brk_starwg.hip)
 int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,

@@ -280,8 +280,10 @@ int make_geom(const long dimlist[3], const long padding[3], const long ghost[3],
 
 namespace brk {
 size_t g_pad_lds = 0;
+int g_diag = 0;
 }
 extern "C" void brk_debug_pad_lds(size_t bytes) { brk::g_pad_lds = bytes; }
+extern "C" void brk_debug_diag(int d) { brk::g_diag = d; }
 
 extern "C" int brk_set_variant(int id, int v) {
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
@@ -387,6 +389,93 @@ int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], 
   return BRK_OK;
 }
 
+
+// ---- registered (immutable) adjacency tables -----------------------------------------------------------------------------------
+// brk_adjacency_register(adj, nbricks): the caller promises that the table does not change until brk_adjacency_release(adj).  The
+// library may then keep derived tables next to it.  So far one kind: per pair of id strides (s1, s2) a bit per brick saying that its
+// six face neighbours are b -+ 1, b -+ s1, b -+ s2 -- what the lexicographic numbering of a box predicts -- which lets the 7-point
+// box kernel skip the adjacency rows of those bricks.  Unregistered tables work exactly as before.
+namespace {
+__global__ void k_regular_mask(const uint32_t *__restrict__ adj, uint32_t nbricks, uint32_t s1, uint32_t s2, uint32_t *__restrict__ mask) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  if (b < nbricks) {
+    const uint32_t *row = adj + (size_t)b * 27;
+    ok = row[adj_slot(0, 0, -1)] == b - 1 && row[adj_slot(0, 0, 1)] == b + 1 && row[adj_slot(0, -1, 0)] == b - s1 &&
+         row[adj_slot(0, 1, 0)] == b + s1 && row[adj_slot(-1, 0, 0)] == b - s2 && row[adj_slot(1, 0, 0)] == b + s2 &&
+         b >= s2 && b + s2 < nbricks; // the predicted ids exist
+  }
+  const unsigned long long m = __ballot(ok);
+  if ((threadIdx.x & 63) == 0) {
+    mask[2 * (b >> 6)] = (uint32_t)m;
+    mask[2 * (b >> 6) + 1] = (uint32_t)(m >> 32);
+  }
+}
+
+struct AdjEntry {
+  const uint32_t *adj;
+  uint32_t nbricks;
+  int device;
+  std::vector<std::pair<std::pair<uint32_t, uint32_t>, uint32_t *>> masks; // (s1, s2) -> device bit mask
+};
+std::mutex g_adj_mutex;
+std::vector<AdjEntry> g_adj;
+
+// the face-regularity mask of a registered table for id strides (s1, s2), built on first use (that call is synchronous on `st`);
+// nullptr (and BRK_OK) when the table is not registered
+int regular_mask(const uint32_t *adj, uint32_t s1, uint32_t s2, hipStream_t st, const uint32_t **out) {
+  *out = nullptr;
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  for (AdjEntry &e : g_adj) {
+    if (e.adj != adj) continue;
+    for (auto &m : e.masks)
+      if (m.first.first == s1 && m.first.second == s2) {
+        *out = m.second;
+        return BRK_OK;
+      }
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    if (device != e.device) return brk_fail(BRK_EINVAL, "adjacency table registered on device %d used on device %d", e.device, device);
+    const uint32_t words = 2 * ((e.nbricks + 255) / 256 * 4);
+    uint32_t *mask = nullptr;
+    HIP_TRY(hipMalloc(&mask, (size_t)words * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_regular_mask, dim3((e.nbricks + 255) / 256), dim3(256), 0, st, adj, e.nbricks, s1, s2, mask);
+    hipError_t r = hipGetLastError();
+    if (r == hipSuccess) r = hipStreamSynchronize(st);
+    if (r != hipSuccess) {
+      (void)hipFree(mask);
+      HIP_TRY(r);
+    }
+    e.masks.push_back({{s1, s2}, mask});
+    *out = mask;
+    return BRK_OK;
+  }
+  return BRK_OK;
+}
+} // namespace
+
+extern "C" int brk_adjacency_register(const uint32_t *adj_dev, uint32_t nbricks) {
+  if (!adj_dev || nbricks == 0) return brk_fail(BRK_EINVAL, "brk_adjacency_register: null table / no bricks");
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  for (const AdjEntry &e : g_adj)
+    if (e.adj == adj_dev) return brk_fail(BRK_EINVAL, "brk_adjacency_register: table %p is registered already", (const void *)adj_dev);
+  g_adj.push_back(AdjEntry{adj_dev, nbricks, device, {}});
+  return BRK_OK;
+}
+
+extern "C" int brk_adjacency_release(const uint32_t *adj_dev) {
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  for (size_t q = 0; q < g_adj.size(); ++q)
+    if (g_adj[q].adj == adj_dev) {
+      for (auto &m : g_adj[q].masks) (void)hipFree(m.second); // hipFree waits for the kernels that still read it
+      g_adj.erase(g_adj.begin() + q);
+      return BRK_OK;
+    }
+  return brk_fail(BRK_EINVAL, "brk_adjacency_release: table %p is not registered", (const void *)adj_dev);
+}
+
 extern "C" int brk_stencil_apply_range(int id, const uint32_t *adj, const double *in, double *out, size_t step,
                                        uint32_t begin, uint32_t end, const double *coeff_host, brk_stream s) {
   if (end < begin) return brk_fail(BRK_EINVAL, "brick range [%u,%u) is reversed", begin, end);
@@ -442,8 +531,11 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
   if ((uint64_t)cnt[0] * cnt[1] * cnt[2] == 0) return BRK_OK;
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
-  if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7)
-    return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s));
+  if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) {
+    const uint32_t *regmask = nullptr; // registered adjacency: bricks whose face neighbours are the predicted ones skip their rows
+    if (int rc = regular_mask(adj, tot[0], tot[0] * tot[1], static_cast<hipStream_t>(s), &regmask)) return rc;
+    return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s), regmask);
+  }
   // other stencils: the same traversal order as an id list, built once per box geometry and kept on the device
   std::lock_guard<std::mutex> lock(g_box_mutex);
   BoxList *e = nullptr;

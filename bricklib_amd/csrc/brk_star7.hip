@@ -154,7 +154,7 @@ enum { kModeRange = 0, kModeList = 1, kModeBox = 2 };
 
 // (brick id, previous, next, active) of wave w of workgroup `g` of XCD `x` in box mode
 __device__ __forceinline__ bool box_entry(const Box &bx, uint32_t x, uint32_t g, uint32_t w, uint32_t &b, bool &has_prev,
-                                          bool &has_next) {
+                                          bool &has_next, uint32_t *slab_edge = nullptr) {
   const uint32_t G = (bx.cnt[0] + 7) / 8, nk = bx.cnt[2];
   const uint32_t j_lo = (bx.cnt[1] * x) / 8, j_hi = (bx.cnt[1] * (x + 1)) / 8;
   const uint32_t rows_x = j_hi - j_lo, full = rows_x / 8, rem = rows_x % 8;
@@ -174,6 +174,7 @@ __device__ __forceinline__ bool box_entry(const Box &bx, uint32_t x, uint32_t g,
   const uint32_t i = ig * 8 + w;
   if (i >= bx.cnt[0]) return false;
   b = bx.base + ((bx.lo[2] + k) * bx.nj_tot + (bx.lo[1] + j_lo + blk * 8 + j)) * bx.ni_tot + bx.lo[0] + i;
+  if (slab_edge) *slab_edge = (blk * 8 + j == 0 ? 1u : 0u) | (blk * 8 + j + 1 == rows_x ? 2u : 0u); // row whose -j / +j neighbour row belongs to another XCD
   has_prev = w > 0;
   has_next = w + 1 < 8 && i + 1 < bx.cnt[0];
   return true;
@@ -219,12 +220,17 @@ namespace {
 #else
 #define BRK_LD_LAST(p) (*(p))
 #endif
-template <int MPI, int NW, int MODE>
+// DIAG (diagnostic builds only, make EXTRA_HIPFLAGS=-DBRK_DIAG, box mode; bits 2..8 give WRONG results on purpose -- what does each
+// source of re-read traffic cost?): 1 = face neighbours by arithmetic on the lexicographic numbering, the adjacency row is not read;
+// 2 = the j-faces of the two rows per XCD slab whose neighbour row belongs to another XCD are read from the brick itself;
+// 4 = every j-face from the brick itself; 8 = every k-face from the brick itself
+template <int MPI, int NW, int MODE, int DIAG = 0>
 __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uint32_t *__restrict__ adj,
                                                                       const double *__restrict__ in,
                                                                       double *__restrict__ out, size_t step,
                                                                       const uint32_t *__restrict__ ids, uint32_t first,
-                                                                      uint32_t n, Box bx, Coeffs cf) {
+                                                                      uint32_t n, Box bx, Coeffs cf,
+                                                                      const uint32_t *__restrict__ regmask) {
   __shared__ double lds[NW * kTile];
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -238,12 +244,14 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
   // (no branches), the adjacency row is requested next, and the 8 loads of the brick itself -- which need only the id --
   // are issued before the adjacency row is waited for.
   STAMP7(t0);
-  uint32_t b = 0, b_prev, b_next;
+  uint32_t b = 0, b_prev, b_next, diag_edge = 0;
   bool active, has_prev = w > 0, has_next = w + 1 < NW && slot + 1 < n;
   if (MODE == kModeBox) {
     static_assert(MODE != kModeBox || NW == 8, "box mode walks rows in groups of 8");
-    active = box_entry(bx, blockIdx.x & 7u, blockIdx.x >> 3, w, b, has_prev, has_next);
+    uint32_t slab_edge = 0;
+    active = box_entry(bx, blockIdx.x & 7u, blockIdx.x >> 3, w, b, has_prev, has_next, DIAG ? &slab_edge : nullptr);
     b = __builtin_amdgcn_readfirstlane(b);
+    if (DIAG) diag_edge = __builtin_amdgcn_readfirstlane(slab_edge);
     b_prev = b - 1;
     b_next = b + 1;
   } else {
@@ -267,11 +275,28 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
 #endif
   STAMP7(t1); // ids known
   if (active) {
-    const Nbr nb = load_nbr(adj, b);
+    // Box mode over a REGISTERED adjacency table (brk_adjacency_register: the caller promised it does not change): bit b of
+    // `regmask` says that the six face neighbours of brick b are the ones the lexicographic numbering predicts, so its adjacency
+    // row is not read at all -- one bit instead of a 108-byte row that straddles two or three 64-byte lines (measured at 512^3,
+    // diagnostic build: the rows cost 60 MB of fabric reads and 3.4 % of the sweep).  Other bricks read their row as always.
+    constexpr bool kMaskable = MODE == kModeBox && !(DIAG & 1);
+    const bool use_mask = kMaskable && regmask != nullptr;
+    uint32_t mword = 0;
+    if (use_mask) mword = (DIAG & 16) ? 0xFFFFFFFFu : regmask[b >> 5]; // DIAG 16: the mask path without its load (timing experiment)
+    Nbr nb{};
+    if (DIAG & 1) nb = Nbr{b - bx.ni_tot * bx.nj_tot, b + bx.ni_tot * bx.nj_tot, b - bx.ni_tot, b + bx.ni_tot, b - 1, b + 1};
+    else if (!use_mask) nb = load_nbr(adj, b);
     const gcptr self = sbase(in + (size_t)b * step);
 #pragma unroll
     for (int k = 0; k < 8; ++k) f.own[k] = BRK_LD_OWN(&self[k * 64 + lane]);
-    __builtin_amdgcn_sched_barrier(0); // own loads are in flight before anything waits for the adjacency row
+    __builtin_amdgcn_sched_barrier(0); // own loads are in flight before anything waits for the mask word / the adjacency row
+    if (use_mask) {
+      if ((mword >> (b & 31u)) & 1u) nb = Nbr{b - bx.ni_tot * bx.nj_tot, b + bx.ni_tot * bx.nj_tot, b - bx.ni_tot, b + bx.ni_tot, b - 1, b + 1};
+      else nb = load_nbr(adj, b);
+    }
+    if ((DIAG & 4) || ((DIAG & 2) && (diag_edge & 1u))) nb.jm = b;
+    if ((DIAG & 4) || ((DIAG & 2) && (diag_edge & 2u))) nb.jp = b;
+    if (DIAG & 8) nb.km = nb.kp = b;
     // siblings: entry slot-1 / slot+1 when they belong to this workgroup
     share_im = has_prev && __builtin_amdgcn_readfirstlane(nb.im) == b_prev;
     share_ip = has_next && __builtin_amdgcn_readfirstlane(nb.ip) == b_next;
@@ -344,7 +369,7 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
     const uint32_t nw = variant == 5 ? 8 : 4;
     const uint32_t wgs = (((n + nw - 1) / nw + 7) / 8) * 8;
 #define BRK_LAUNCH_WG(M, W, I) \
-  hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf)
+  hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf, nullptr)
 #define BRK_LAUNCH_WG_K(K, W)                      \
   do {                                            \
     if (ids) BRK_LAUNCH_WG(K, W, kModeList);      \
@@ -376,7 +401,8 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
 
 // Box mode (brk_stencil_apply_box): no id list; see struct Box.
 int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, double *out, size_t step, uint32_t base,
-                     const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const Coeffs &cf, hipStream_t st) {
+                     const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const Coeffs &cf, hipStream_t st,
+                     const uint32_t *regmask) {
   Box bx{base, tot[0], tot[1], {lo[0], lo[1], lo[2]}, {cnt[0], cnt[1], cnt[2]}};
   const uint32_t G = (cnt[0] + 7) / 8;
   uint32_t per_xcd = 0;
@@ -386,12 +412,22 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
   }
   if (per_xcd == 0) return BRK_OK;
   const uint32_t n = cnt[0] * cnt[1] * cnt[2];
+#ifdef BRK_DIAG
+  if (g_diag) {
+#define BRK_DIAG_CASE(D) \
+  if (g_diag == D) hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox, D>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask)
+    BRK_DIAG_CASE(16); BRK_DIAG_CASE(1); BRK_DIAG_CASE(2); BRK_DIAG_CASE(3); BRK_DIAG_CASE(4); BRK_DIAG_CASE(5); BRK_DIAG_CASE(8); BRK_DIAG_CASE(12); BRK_DIAG_CASE(13);
+#undef BRK_DIAG_CASE
+    HIP_TRY(hipGetLastError());
+    return BRK_OK;
+  }
+#endif
   if (stencil_id == BRK_MPI7)
-    hipLaunchKernelGGL((k_s7_wg<kMpi, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+    hipLaunchKernelGGL((k_s7_wg<kMpi, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask);
   else if (stencil_id == BRK_COND7)
-    hipLaunchKernelGGL((k_s7_wg<kCond, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+    hipLaunchKernelGGL((k_s7_wg<kCond, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask);
   else
-    hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf);
+    hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask);
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

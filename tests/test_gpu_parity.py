@@ -1138,3 +1138,48 @@ def test_strong_cycle_baseline_shape_512_128(oracle, dev):
             err = max(np.abs(gg[a:a + 8, b:b + 8, c:c + 8].cpu().numpy() - want[a:a + 8, b:b + 8, c:c + 8]).max()
                       for a in (0, sub - 8) for b in (0, sub - 8) for c in (0, sub - 8))
         assert err <= TOL, (q, err)
+
+
+def test_registered_adjacency_box_form_is_bit_identical(oracle, dev):
+    """brk_adjacency_register (the BrickInfo of init_grid / getBrickInfo registers its device table): the 7-point box kernels then
+    skip the adjacency rows of bricks whose face neighbours are the predicted ones.  Same bits as the unregistered path -- also
+    where prediction fails: the inner box of a BrickDecomp (its border bricks point into the region-ordered surface), a periodic
+    wrap written into the table, and after release / re-registration of a rewritten table."""
+    from bricklib_amd._lib import check, lib
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    for case in ("init_grid", "decomp_inner", "wrapped"):
+        if case == "decomp_inner":
+            d = bl.BrickDecomp((48, 40, 56))
+            adj = d.adj.copy()
+            nb = [x // 8 - 2 for x in (48, 40, 56)]
+            box = (1, nb, (0, 0, 0), nb)
+        else:
+            shape = (12, 9, 7)
+            grid, info0 = bl.init_grid(shape, None)
+            adj = info0.adj_host.copy()
+            if case == "wrapped":       # i-periodic interior: the +i neighbour of the last interior column is the first one
+                g3 = grid.reshape(shape[2], shape[1], shape[0])
+                for k in range(shape[2]):
+                    for j in range(shape[1]):
+                        adj[g3[k, j, shape[0] - 2], 14] = g3[k, j, 1]
+                        adj[g3[k, j, 1], 12] = g3[k, j, shape[0] - 2]
+            box = (0, shape, (1, 1, 1), tuple(x - 2 for x in shape))
+        nbricks = adj.shape[0]
+        stA = bl.BrickStorage.allocate(nbricks, 512, dev)
+        stA.dat.copy_(torch.from_numpy(rng.random(nbricks * 512)))
+        outs = []
+        raw = grid_to_device(adj.reshape(-1), dev).reshape(-1, 27)           # a device tensor: not registered
+        for info in (bl.BrickInfo(raw), bl.BrickInfo(adj, dev)):               # unregistered, registered
+            for name in ("7pt", "mpi7pt"):
+                stB = bl.BrickStorage.allocate(nbricks, 512, dev)
+                bl.apply_stencil(name, bl.Brick(info, stA, 0), bl.Brick(info, stB, 0), box=box, coeff=oracle.coeffs(129, 1) if name == "7pt" else None)
+                outs.append(stB.dat.clone())
+        assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3]), case
+        assert outs[0].abs().max().item() > 0
+    # the promise is per table: duplicate registration and unknown release are errors; release, rewrite, register again
+    t = grid_to_device(adj.reshape(-1), dev)
+    check(lib.brk_adjacency_register(C.c_void_p(t.data_ptr()), nbricks))
+    assert lib.brk_adjacency_register(C.c_void_p(t.data_ptr()), nbricks) != 0
+    check(lib.brk_adjacency_release(C.c_void_p(t.data_ptr())))
+    assert lib.brk_adjacency_release(C.c_void_p(t.data_ptr())) != 0

@@ -158,22 +158,28 @@ __global__ __launch_bounds__(256) void k_stream2_persist(const double *in, doubl
 }
 
 int main(int argc, char **argv) {
-  int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1;
-  bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false;
+  int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1, rounds = 2;
+  bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false, reg = false;
   std::vector<int> variants = {1, 2, 5};
   for (int a = 1; a < argc; ++a) {
     std::string o = argv[a];
     if (o == "-n") N = atoi(argv[++a]);
     else if (o == "-s") sid = atoi(argv[++a]);
     else if (o == "-i") iters = atoi(argv[++a]);
+    else if (o == "-r2") rounds = atoi(argv[++a]); // interleaved rounds over the variant list
     else if (o == "-d") decomp = true;
     else if (o == "-r") shuffle = true;
     else if (o == "-b") boxmode = true;     // brk_stencil_apply_box over the interior (lexi layouts only)
     else if (o == "-S") separate = true;   // lexicographic list but two storages (step 512)
     else if (o == "-o") order = atoi(argv[++a]); // 0 lexi; J>0: per-XCD j-slabs of 8 rows, swept in sub-blocks of J rows over all k
     else if (o == "-k") kstack = atoi(argv[++a]); // with -o: workgroup = 8 i-bricks x kstack k-levels
+    else if (o == "-R") reg = true;        // brk_adjacency_register: the table is promised immutable
     else if (o == "-c") stream = true;     // also run the streaming-ceiling kernels
-    else if (o == "-L") {                  // unused dynamic LDS per launch: fewer workgroups resident per CU (occupancy experiments)
+    else if (o == "-D") {                  // diagnostic builds of libbrk.so: timing experiment of the 7-point box kernel
+      typedef void (*diag_fn)(int);
+      diag_fn dg = (diag_fn)dlsym(RTLD_DEFAULT, "brk_debug_diag");
+      if (dg) dg(atoi(argv[++a]));
+    } else if (o == "-L") {                  // unused dynamic LDS per launch: fewer workgroups resident per CU (occupancy experiments)
       typedef void (*pad_fn)(size_t);
       pad_fn pad = (pad_fn)dlsym(RTLD_DEFAULT, "brk_debug_pad_lds");
       if (pad) pad((size_t)atol(argv[++a]));
@@ -249,6 +255,7 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&adj_d, adj.size() * 4));
   CK(hipMalloc(&res_d, 8));
   CK(hipMemcpy(adj_d, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
+  if (reg) BK(brk_adjacency_register(adj_d, nbricks));
   if (!ids.empty()) {
     CK(hipMalloc(&ids_d, ids.size() * 4));
     CK(hipMemcpy(ids_d, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
@@ -314,8 +321,19 @@ int main(int argc, char **argv) {
              16.0 * cells / ms / 1e6 / 80.0);
     }
   }
-  for (int round = 0; round < 2; ++round)
-    for (int v : variants) {
+  // variant codes >= 100 (A/B inside one process, interleaved rounds): 1xx = adjacency registered (brk_adjacency_register) for
+  // that variant's launches, 2xx = diagnostic build, diag 1, 3xx = registered + diag 16
+  typedef void (*diag_fn2)(int);
+  diag_fn2 set_diag = (diag_fn2)dlsym(RTLD_DEFAULT, "brk_debug_diag");
+  for (int round = 0; round < rounds; ++round)
+    for (int vcode : variants) {
+      const int v = vcode % 100, mode = vcode / 100;
+      if (mode == 1 || mode == 3) BK(brk_adjacency_register(adj_d, nbricks));
+      if (set_diag && mode >= 2) set_diag(mode == 2 ? 1 : 16);
+      struct Undo {
+        int mode; const uint32_t *adj; diag_fn2 sd;
+        ~Undo() { if (mode == 1 || mode == 3) { (void)hipDeviceSynchronize(); brk_adjacency_release(adj); } if (sd && mode >= 2) sd(0); }
+      } undo{mode, adj_d, set_diag};
       BK(brk_set_variant(sid, v));
       for (int w = 0; w < 3; ++w) launch(st_out);
       CK(hipEventRecord(e0));
@@ -331,7 +349,7 @@ int main(int argc, char **argv) {
       CK(hipMemcpy(&bits, res_d, 8, hipMemcpyDeviceToHost));
       double md;
       memcpy(&md, &bits, 8);
-      printf("variant %d  %.4f ms  %.1f GStencil/s  %.0f GB/s (%.1f%% of 8 TB/s)  maxdiff_vs_v1 %.3g\n", v, ms,
+      printf("variant %d  %.4f ms  %.1f GStencil/s  %.0f GB/s (%.1f%% of 8 TB/s)  maxdiff_vs_v1 %.3g\n", vcode, ms,
              cells / ms / 1e6, 16.0 * cells / ms / 1e6, 16.0 * cells / ms / 1e6 / 80.0, md);
       fflush(stdout);
       // diagnostic builds of libbrk.so (make -C bricklib_amd/csrc EXTRA_HIPFLAGS=-DBRK_STAMP) export per-phase shader-clock
