@@ -65,6 +65,15 @@ extern "C" int brk_debug_stamps_by_wave(unsigned long long out[4][8]) {
 #endif
 namespace {
 
+// ablation experiments (diagnostic builds only, make EXTRA_HIPFLAGS=-DBRK_DIAG, tools/kbench -D bits; WRONG results on purpose):
+//   1 no accumulation (the centre value is stored)   2 no edge/corner gathers   4 no k-/j-face loads   8 neighbours taken as linked
+//   by position in the group (the rows of the list neighbours are not read)   16 no i-side loads at group ends   32 own brick not loaded
+#ifdef BRK_DIAG
+#define DG(x) ((diag & (x)) != 0)
+#else
+#define DG(x) false
+#endif
+
 template <int KIND>
 struct DenseTile {
   static constexpr int R = CubeTraits<KIND>::R;
@@ -174,7 +183,7 @@ __device__ __forceinline__ bool linked(uint32_t rl, uint32_t rr, int lane) {
 template <int KIND, int NW, int OCC, int PIPE = 1>
 __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
-    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
+    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf, int diag) {
   constexpr int R = CubeTraits<KIND>::R;
   using TL = DenseTile<KIND>;
   using X = DX<KIND>;
@@ -210,6 +219,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     }
   }
   STAMP(t0);
+  if (DG(128)) __builtin_amdgcn_s_setprio(3); // experiment: the fetch phase ahead, the compute phase behind
   const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(id_of(slot)) : BRK_LIST_SKIP;
   const bool active = b != BRK_LIST_SKIP;
   bool link_l = false, link_r = false, brk_l = false;
@@ -244,18 +254,29 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     // below (links, face addresses) waits for the rows -- behind the 4 KiB of the brick that wait is a full HBM round trip
     // (in-kernel stamps: 8500 of a wave's 15000 cycles went by before the face loads were issued)
     const uint32_t arow = adj[(size_t)b * 27 + l27]; // lanes 0..26: the adjacency row
-    const uint32_t prow = adj[(size_t)(b_prev != BRK_LIST_SKIP ? b_prev : b) * 27 + l27];
-    const uint32_t nrow = adj[(size_t)(b_next != BRK_LIST_SKIP ? b_next : b) * 27 + l27];
+    uint32_t prow = 0, nrow = 0;
+    if (!DG(8)) {
+      prow = adj[(size_t)(b_prev != BRK_LIST_SKIP ? b_prev : b) * 27 + l27];
+      nrow = adj[(size_t)(b_next != BRK_LIST_SKIP ? b_next : b) * 27 + l27];
+    }
     __builtin_amdgcn_sched_barrier(0);
     const gcptr self = sbase(in + (size_t)b * step);
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (!LD16) own[k] = self[k * 64 + lane];
+    for (int k = 0; k < 8; ++k) {
+      own[k] = 0.5;
+      if (!LD16 && !DG(32)) own[k] = self[k * 64 + lane];
+    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (LD16) own2[q] = *(gc2)(self + q * 128 + 2 * lane);
-    link_l = b_prev != BRK_LIST_SKIP && linked(prow, arow, lane);
-    link_r = b_next != BRK_LIST_SKIP && linked(arow, nrow, lane);
+    for (int q = 0; q < 4; ++q) {
+      own2[q] = d2{0.5, 0.25};
+      if (LD16 && !DG(32)) own2[q] = *(gc2)(self + q * 128 + 2 * lane);
+    }
+    if (DG(8)) {
+      link_l = b_prev != BRK_LIST_SKIP, link_r = b_next != BRK_LIST_SKIP;
+    } else {
+      link_l = b_prev != BRK_LIST_SKIP && linked(prow, arow, lane);
+      link_r = b_next != BRK_LIST_SKIP && linked(arow, nrow, lane);
+    }
     brk_l = b_prev != BRK_LIST_SKIP && !link_l; // two active neighbours that cannot share
     STAMP(t0b);
 #ifdef BRK_STAMP
@@ -274,24 +295,25 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       fkm[r] = fkp[r] = 0.0;
-      if (!LD16 || (KF16H && !TL::has_plane(r))) fkm[r] = p_km[(8 - R + r) * 64 + lane];
-      if (!LD16 || (KF16H && !TL::has_plane(R + 8 + r))) fkp[r] = p_kp[r * 64 + lane];
+      if (!DG(4) && (!LD16 || (KF16H && !TL::has_plane(r)))) fkm[r] = p_km[(8 - R + r) * 64 + lane];
+      if (!DG(4) && (!LD16 || (KF16H && !TL::has_plane(R + 8 + r)))) fkp[r] = p_kp[r * 64 + lane];
       fjm[r] = fjp[r] = fim[r] = fip[r] = 0.0;
-      if (!W16 && !LD16) {
+      if (!W16 && !LD16 && !DG(4)) {
         fjm[r] = p_jm[hi * 64 + (8 - R + r) * 8 + lo];
         fjp[r] = p_jp[hi * 64 + r * 8 + lo];
       }
     }
-    if (KF16) {
+    if (KF16 && !DG(4)) {
       km2 = *(gc2)(p_km + 6 * 64 + 2 * lane);
       kp2 = *(gc2)(p_kp + 2 * lane);
     }
-    if (KF16H) kh2 = *(gc2)((lp ? p_kp : p_km + 7 * 64) + 2 * l5);
-    if (LD16 && R == 1) jh2 = *(gc2)((lp ? p_jp : p_jm + 56) + (l5 >> 2) * 64 + 2 * (l5 & 3)); // row 7 below / row 0 above of plane l5/4
-    if (W16) { // lane (k = hi, chunk lo): rows 6, 7 / 0, 1 of plane k are 128 contiguous bytes
+    if (KF16H && !DG(4)) kh2 = *(gc2)((lp ? p_kp : p_km + 7 * 64) + 2 * l5);
+    if (LD16 && R == 1 && !DG(4)) jh2 = *(gc2)((lp ? p_jp : p_jm + 56) + (l5 >> 2) * 64 + 2 * (l5 & 3)); // row 7 below / row 0 above of plane l5/4
+    if (W16 && !DG(4)) { // lane (k = hi, chunk lo): rows 6, 7 / 0, 1 of plane k are 128 contiguous bytes
       jm2 = *(gc2)(p_jm + hi * 64 + 48 + 2 * lo);
       jp2 = *(gc2)(p_jp + hi * 64 + 2 * lo);
     }
+    if (DG(16)) link_l = link_r = true; // from here on only the loads of the i-sides look at the links (the tiles' F slots stay unwritten)
     if (!link_l) {
       const gcptr p_im = sbase(in + (size_t)n_im * step);
       if (W16) im2 = *(gc2)(p_im + hi * 64 + lo * 8 + 6); // lane (k = hi, j = lo): columns 6, 7 of its row
@@ -307,6 +329,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
         if (!W16) fip[r] = p_ip[hi * 64 + lo * 8 + r];
     }
     auto gather = [&](int t) {
+      if (DG(2)) {
+        xv[t] = 0.0, xv2[t] = d2{0.0, 0.0};
+        return;
+      }
       const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((xd[t] >> 16) & 31u) << 2), (int)arow);
       if (X::PAIR) xv2[t] = xd[t] != 0xFFFFFFFFu ? *(const d2 *)(in + (size_t)nb * step + ((xd[t] >> 21) & 511u)) : d2{0.0, 0.0};
       else xv[t] = xd[t] != 0xFFFFFFFFu ? in[(size_t)nb * step + ((xd[t] >> 21) & 511u)] : 0.0;
@@ -413,6 +439,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     }
 #endif
     if (mine) {
+      if (DG(128)) __builtin_amdgcn_s_setprio(0);
+      if (DG(64)) __builtin_amdgcn_s_setprio(3); // experiment: the compute phase ahead of the other waves of its SIMD
       // per-lane offset of column lo+di relative to the row start: own tile, or the slot on that side
       int col[2 * R + 1];
 #pragma unroll
@@ -420,7 +448,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
         const int c = lo + di;
         col[di + R] = c < 0 ? -E + c + 8 : (c > 7 ? roff + c - 8 : c);
       }
-      if (KIND == kDiamond25) {
+      if (DG(1)) { // ablation: no accumulation, the centre values leave as they came
+#pragma unroll
+        for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], tile[TL::has_plane(k + R) ? TL::at(k + R, hi + R, lo) : 0] + (double)col[0]);
+      } else if (KIND == kDiamond25) {
         const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
         diamond25_accumulate<TL::T * 8, 8, PIPE == 1>(tile + TL::at(0, hi + R, 0), co, cf, dst, lane, fkm[0], fkp[R - 1]);
       } else if (KIND == kCube125) {
@@ -470,35 +501,32 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 // software-pipelined rolled loop (2 waves/SIMD)
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
-  const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8, wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
-  if ((stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2) && variant == 2) { // plane loop without read-ahead
-    hipLaunchKernelGGL((k_cube_dense<kDiamond25, 4, 4, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else if (stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2) {
-    hipLaunchKernelGGL((k_cube_dense<kDiamond25, 4, 4>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else if (stencil_id == BRK_27PT_COEFF) {
-    if (variant == 5)
-      hipLaunchKernelGGL((k_cube_dense<kCube27, 8, 4>), dim3(wgs8), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-    else
-      hipLaunchKernelGGL((k_cube_dense<kCube27, 4, 5>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else if (variant == 6) {
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 2>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else if (variant == 7) {
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 8, 2>), dim3(wgs8), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else if (variant == 11) { // row-pipelined plane loop with 5 rows in flight (spills)
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 4>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-#ifdef BRK_DIAG // occupancy experiment: the default kernel with unused dynamic LDS -> 2 groups (8 waves) / 1 group (4 waves) per CU
-  } else if (variant == 13 || variant == 14) {
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 5>), dim3(wgs4), dim3(256), variant == 13 ? 26000 : 60000, st, adj, in, out, step, ids, first, n, cf);
-#endif
-  } else if (variant == 10) { // input-side accumulation, row-pipelined plane loop, 3 rows of LDS reads in flight
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 3>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else if (variant == 9) {
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else if (variant == 5) { // fully unrolled plane loop, reads of a plane in one burst (the round-1 default)
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 2>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else { // default (0, 12): output-side j-shift -- 60 + 40 LDS reads per lane, the shift through a wave-private slot
-    hipLaunchKernelGGL((k_cube_dense<kCube125, 4, 3, 5>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+  const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8;
+  const bool x2 = stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2;
+#define BRK_CD(KIND, NW, OCC, PIPE, WGS, LDS) \
+  hipLaunchKernelGGL((k_cube_dense<KIND, NW, OCC, PIPE>), dim3(WGS), dim3(64 * NW), LDS, st, adj, in, out, step, ids, first, n, cf, g_diag)
+#ifdef BRK_VARIANTS
+  const uint32_t wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
+  bool done = true;
+  if (x2 && variant == 2) BRK_CD(kDiamond25, 4, 4, 0, wgs4, g_pad_lds);                       // plane loop without read-ahead
+  else if (stencil_id == BRK_27PT_COEFF && variant == 5) BRK_CD(kCube27, 8, 4, 1, wgs8, g_pad_lds);
+  else if (stencil_id == BRK_MPI125 && variant == 6) BRK_CD(kCube125, 4, 2, 1, wgs4, g_pad_lds);
+  else if (stencil_id == BRK_MPI125 && variant == 7) BRK_CD(kCube125, 8, 2, 1, wgs8, g_pad_lds);
+  else if (stencil_id == BRK_MPI125 && variant == 11) BRK_CD(kCube125, 4, 3, 4, wgs4, g_pad_lds); // row-pipelined plane loop, 5 rows in flight (spills)
+  else if (stencil_id == BRK_MPI125 && variant == 10) BRK_CD(kCube125, 4, 3, 3, wgs4, g_pad_lds); // input-side accumulation, row-pipelined plane loop
+  else if (stencil_id == BRK_MPI125 && variant == 9) BRK_CD(kCube125, 4, 3, 0, wgs4, g_pad_lds);
+  else if (stencil_id == BRK_MPI125 && variant == 5) BRK_CD(kCube125, 4, 3, 2, wgs4, g_pad_lds);  // fully unrolled plane loop (the round-1 default)
+  else done = false;
+  if (done) {
+    HIP_TRY(hipGetLastError());
+    return BRK_OK;
   }
+#endif
+  (void)variant;
+  if (x2) BRK_CD(kDiamond25, 4, 4, 1, wgs4, g_pad_lds);
+  else if (stencil_id == BRK_27PT_COEFF) BRK_CD(kCube27, 4, 5, 1, wgs4, g_pad_lds);
+  else BRK_CD(kCube125, 4, 3, 5, wgs4, g_pad_lds); // output-side j-shift: 60 + 40 LDS reads per lane, the shift through a wave-private slot
+#undef BRK_CD
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

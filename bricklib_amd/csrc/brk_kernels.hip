@@ -33,8 +33,10 @@ __device__ __forceinline__ uint32_t wave_slot(uint32_t n) {
 
 // ================================================================================================================
 // Generic kernels: one wave per brick, 4 waves per workgroup; the per-brick bodies live in include/brick-device.h
-// (shared with user kernels that call brk::brick_apply from a rewritten brick(...) line).
+// (shared with user kernels that call brk::brick_apply from a rewritten brick(...) line).  Earlier generation: compiled
+// only with -DBRK_VARIANTS (make VARIANTS=1), for A/B runs in tools/kbench and the variant parity tests.
 // ================================================================================================================
+#ifdef BRK_VARIANTS
 template <int KIND>
 __global__ __launch_bounds__(kWG) void k_star(const uint32_t *__restrict__ adj, const double *__restrict__ in,
                                                double *__restrict__ out, size_t step,
@@ -66,6 +68,8 @@ __global__ __launch_bounds__(64 * WPW) void k_cube(const uint32_t *__restrict__ 
   cube_brick<KIND>(lds + (threadIdx.x >> 6) * CubeTile<CubeTraits<KIND>::R>::ELEMS, adj, in, out, step, b, cf,
                    threadIdx.x & 63);
 }
+
+#endif // BRK_VARIANTS
 
 // stencil given as data (brk_stencil_apply_taps): one wave per brick, generic staging, one LDS read + FMA per tap and plane
 template <int R, int WPW>
@@ -218,17 +222,13 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   const int var = g_variant[id].load(std::memory_order_relaxed);
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
-  const uint32_t wgs = (n + kWavesPerWG - 1) / kWavesPerWG;
-  const dim3 grid(((wgs + 7) / 8) * 8), block(kWG);
   hipStream_t st = static_cast<hipStream_t>(s);
-  // 7-point sweeps: specialised kernels (brk_star7.hip) unless variant 1 (generic star kernel) is requested
+  // default kernels: 7-point family in brk_star7.hip, 13-/25-point in brk_starwg.hip, 27-/125-point and the fused double
+  // 7-point sweep in brk_cubedense.hip.  Builds with -DBRK_VARIANTS also carry the earlier generations (brk_set_variant).
+#ifdef BRK_VARIANTS
   if ((id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) && var != 1)
     return launch_star7(id, var == 0 ? kDefaultStar7Variant : var, adj, in, out, step, ids, first, n, cf, st);
   if ((id == BRK_MPI13 || id == BRK_MPI25) && var != 1) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st);
-  // 27/125-pt: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip) by default; variant 1 = generic
-  // one-wave kernel, 27-pt variant 2 and 125-pt variants 2/4/8 = padded tiles with shared i-halos (brk_cubewg.hip),
-  // 125-pt variant 3 = generic kernel with 4 waves per workgroup.  Measured at 512^3 (profiles/): 27-pt 0.555 (padded,
-  // 8 waves) -> 0.43 ms; 125-pt 1.06 (generic) -> 0.70 ms.
   if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = var;
@@ -236,7 +236,9 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
     if ((id == BRK_27PT_COEFF && v == 2) || (id == BRK_MPI125 && (v == 2 || v == 4 || v == 8)))
       return launch_cube_wg(id, id == BRK_MPI125 ? v : 8, adj, in, out, step, ids, first, n, cf, st);
   }
-  switch (id) {
+  const uint32_t wgs = (n + kWavesPerWG - 1) / kWavesPerWG;
+  const dim3 grid(((wgs + 7) / 8) * 8), block(kWG);
+  switch (id) { // variant 1: the generic one-wave kernels (3: 125-point with 4 waves per workgroup)
   case BRK_7PT_COEFF: hipLaunchKernelGGL(k_star<kStar7Coeff>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_COND7: hipLaunchKernelGGL(k_star<kStarCond7>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
   case BRK_MPI7: hipLaunchKernelGGL(k_star<kStarMpi7>, grid, block, 0, st, adj, in, out, step, ids, first, n, cf); break;
@@ -246,12 +248,18 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   case BRK_MPI125:
     if (var == 3)
       hipLaunchKernelGGL((k_cube<kCube125, 4>), grid, block, 0, st, adj, in, out, step, ids, first, n, cf);
-    else // variant 1
+    else
       hipLaunchKernelGGL((k_cube<kCube125, 1>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, cf);
     break;
   }
   HIP_TRY(hipGetLastError());
   return BRK_OK;
+#else
+  (void)var;
+  if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) return launch_star7(id, kDefaultStar7Variant, adj, in, out, step, ids, first, n, cf, st);
+  if (id == BRK_MPI13 || id == BRK_MPI25) return launch_star_wg(id, 0, adj, in, out, step, ids, first, n, cf, st);
+  return launch_cube_dense(id, 0, adj, in, out, step, ids, first, n, cf, st);
+#endif
 }
 
 int make_geom(const long dimlist[3], const long padding[3], const long ghost[3], IterGeom &g, long &nb) {
@@ -287,6 +295,9 @@ extern "C" void brk_debug_diag(int d) { brk::g_diag = d; }
 
 extern "C" int brk_set_variant(int id, int v) {
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
+#ifndef BRK_VARIANTS
+  if (v != 0) return brk_fail(BRK_EINVAL, "kernel variant %d: this build carries the default kernels only (make -C bricklib_amd/csrc VARIANTS=1 adds the earlier generations)", v);
+#endif
   g_variant[id] = v;
   return BRK_OK;
 }

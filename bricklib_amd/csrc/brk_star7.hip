@@ -114,7 +114,8 @@ __device__ __forceinline__ void compute_store(const double *tile, const Faces &f
   }
 }
 
-// ---- variant 2: one brick per wave ------------------------------------------------------------------------------
+// ---- variant 2: one brick per wave (earlier generation, -DBRK_VARIANTS builds only) --------------------------------
+#ifdef BRK_VARIANTS
 template <int MPI>
 __global__ __launch_bounds__(kWG, 6) void k_s7(const uint32_t *__restrict__ adj, const double *__restrict__ in,
                                                 double *__restrict__ out, size_t step,
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(kWG, 6) void k_s7(const uint32_t *__restrict__ adj,
   wave_lds_sync();
   compute_store<MPI>(tile, f, out + (size_t)b * step, lane, cf);
 }
+#endif // BRK_VARIANTS
 
 // ---- variant 5/6: workgroup of NW waves = NW consecutive list entries; i-faces shared through LDS ------------------
 // Measured on MI355X (profiles/): the two i-face gathers (64 lanes x 8 B at 64-B stride, touching every line of the
@@ -365,9 +367,8 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
 int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step,
                  const uint32_t *ids, uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
   const int kind = stencil_id == BRK_MPI7 ? kMpi : (stencil_id == BRK_COND7 ? kCond : kCoeff);
-  if (variant == 5 || variant == 6) { // workgroups of 8 / 4 waves sharing i-faces
-    const uint32_t nw = variant == 5 ? 8 : 4;
-    const uint32_t wgs = (((n + nw - 1) / nw + 7) / 8) * 8;
+  // workgroups of 8 waves sharing i-faces (variant 5, the default); -DBRK_VARIANTS builds: 6 = 4-wave groups, 2 = one brick per
+  // wave with every face gathered
 #define BRK_LAUNCH_WG(M, W, I) \
   hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf, nullptr)
 #define BRK_LAUNCH_WG_K(K, W)                      \
@@ -381,12 +382,11 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
     else if (kind == kCond) BRK_LAUNCH_WG_K(kCond, W); \
     else BRK_LAUNCH_WG_K(kCoeff, W);              \
   } while (0)
-    if (variant == 5) BRK_LAUNCH_WG_W(8);
-    else BRK_LAUNCH_WG_W(4);
-#undef BRK_LAUNCH_WG_W
-#undef BRK_LAUNCH_WG_K
-#undef BRK_LAUNCH_WG
-  } else { // variant 2: one brick per wave, every face gathered
+#ifdef BRK_VARIANTS
+  if (variant == 6) {
+    const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
+    BRK_LAUNCH_WG_W(4);
+  } else if (variant == 2) {
     const uint32_t wgs = (((n + kWavesPerWG - 1) / kWavesPerWG + 7) / 8) * 8;
     if (kind == kMpi)
       hipLaunchKernelGGL(k_s7<kMpi>, dim3(wgs), dim3(kWG), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
@@ -394,7 +394,16 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
       hipLaunchKernelGGL(k_s7<kCond>, dim3(wgs), dim3(kWG), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
     else
       hipLaunchKernelGGL(k_s7<kCoeff>, dim3(wgs), dim3(kWG), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+  } else
+#endif
+  {
+    (void)variant;
+    const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
+    BRK_LAUNCH_WG_W(8);
   }
+#undef BRK_LAUNCH_WG_W
+#undef BRK_LAUNCH_WG_K
+#undef BRK_LAUNCH_WG
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

@@ -216,31 +216,38 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
   // 0.408 ms; 25-pt (12 KiB of LDS per wave, 12 waves/CU either way) 4 waves 0.502 ms vs 2 waves 0.507 ms -- since every line of a
   // face is requested once the 25-pt i-faces are the dearer part (before that: 2 waves 0.532 vs 4 waves 0.545).  Variant 2 = the
   // other group size.
-  if (stencil_id == BRK_MPI13 && variant != 2) {
-    const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 4, 5>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else if (stencil_id == BRK_MPI13) {
+  // defaults: 13-point 4-wave groups (5 per CU), 25-point 4-wave groups; -DBRK_VARIANTS builds: variant 2 = the other group size
+#ifdef BRK_VARIANTS
+  if (stencil_id == BRK_MPI13 && variant == 2) {
     const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
     hipLaunchKernelGGL((k_star_wg<kStarMpi13, 8, 4>), dim3(wgs), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-#ifdef BRK_DIAG // diagnostic build only (make EXTRA_HIPFLAGS=-DBRK_DIAG): these variants compute WRONG results on purpose
-  } else if (variant >= 7 && variant <= 9) { // timing experiments: 7 = no k-face loads, 8 = no j-face loads, 9 = neither (wrong results)
-    const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
-    if (variant == 7) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 1>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-    else if (variant == 8) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 2>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-    else hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 3>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else if (variant >= 10 && variant <= 12) { // 10 = k-faces read from the brick itself, 11 = j-faces, 12 = both (wrong results)
-    const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
-    if (variant == 10) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 4>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-    else if (variant == 11) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 8>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-    else hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, 12>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-#endif
-  } else if (variant == 2) {
+    HIP_TRY(hipGetLastError());
+    return BRK_OK;
+  }
+  if (stencil_id == BRK_MPI25 && variant == 2) {
     const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
     hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-  } else {
-    const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 4, 3>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    HIP_TRY(hipGetLastError());
+    return BRK_OK;
   }
+#endif
+#ifdef BRK_DIAG // diagnostic build only (make EXTRA_HIPFLAGS=-DBRK_DIAG): these variants compute WRONG results on purpose
+  if (stencil_id == BRK_MPI25 && variant >= 7 && variant <= 12) {
+    // timing experiments: 7 = no k-face loads, 8 = no j-face loads, 9 = neither; 10 = k-faces read from the brick itself, 11 = j-faces, 12 = both
+    const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
+#define BRK_DIAG25(V, D) if (variant == V) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, D>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf)
+    BRK_DIAG25(7, 1); BRK_DIAG25(8, 2); BRK_DIAG25(9, 3); BRK_DIAG25(10, 4); BRK_DIAG25(11, 8); BRK_DIAG25(12, 12);
+#undef BRK_DIAG25
+    HIP_TRY(hipGetLastError());
+    return BRK_OK;
+  }
+#endif
+  (void)variant;
+  const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
+  if (stencil_id == BRK_MPI13)
+    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 4, 5>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+  else
+    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 4, 3>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

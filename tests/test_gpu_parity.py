@@ -13,6 +13,14 @@ from oracle.oracle import ST_7PT_COEFF, ST_27PT_COEFF, ST_MPI7, ST_MPI13, ST_MPI
 
 pytestmark = pytest.mark.gpu
 
+
+def _set_variant_or_skip(lib, sid, variant):
+    """the earlier kernel generations are compiled only with `make -C bricklib_amd/csrc VARIANTS=1` (tools/kbench A/B runs); the
+    default build carries one kernel per stencil, and a variant test then has nothing to run"""
+    if variant != 0 and lib.brk_set_variant(sid, variant) != 0:
+        pytest.skip("kernel variants are not part of this build (make -C bricklib_amd/csrc VARIANTS=1)")
+    assert lib.brk_set_variant(sid, variant) == 0
+
 TOL = 1e-12   # fp64, <=125 terms of magnitude <1: observed ~1e-15; north-star bar is 1e-10
 NAMES = {"7pt": ST_7PT_COEFF, "27pt": ST_27PT_COEFF, "mpi7pt": ST_MPI7, "mpi13pt": ST_MPI13, "mpi25pt": ST_MPI25,
          "mpi125pt": ST_MPI125}
@@ -254,7 +262,7 @@ def test_star7_kernel_variants(oracle, dev, name, variant):
     sid = bl.STENCILS[name]
     coeff = oracle.coeffs(129, 1) if name == "7pt" else None
     try:
-        assert lib.brk_set_variant(sid, variant) == 0
+        _set_variant_or_skip(lib, sid, variant)
         # list form on the single/ layout
         grid, grid_dev, bInfo, arr, st, bIn, ids = single_setup(oracle, dev, 48, 1024)
         hin = np.ascontiguousarray(st.dat.cpu().numpy().reshape(-1, 1024)[:, :512]).reshape(-1)
@@ -521,7 +529,7 @@ def test_cond_stencil(oracle, golden, dev, variant):
     from bricklib_amd._lib import lib
     from oracle.oracle import ST_COND7
     try:
-        lib.brk_set_variant(6, variant)
+        _set_variant_or_skip(lib, 6, variant)
         z = golden("cond_N16")
         grid, grid_dev, bInfo, arr, st, bIn, ids = single_setup(oracle, dev, 16, 512)
         st.dat -= 0.5
@@ -554,7 +562,7 @@ def test_cube_kernel_variants(oracle, dev, name, variant):
     sid = bl.STENCILS[name]
     coeff = oracle.coeffs(129, 1) if name == "27pt" else None
     try:
-        assert lib.brk_set_variant(sid, variant) == 0
+        _set_variant_or_skip(lib, sid, variant)
         grid, info = bl.init_grid((8, 7, 6), dev)
         st = bl.BrickStorage.allocate(info.nbricks, 512, dev)
         st.dat.uniform_(0.0, 1.0)

@@ -1,0 +1,111 @@
+#!/bin/bash
+# tools/gpu.sh -- ONE parametrised runner for everything that is run on the GPU box from the repository root
+# (`gpurun -- 'bash tools/gpu.sh <recipe> [args]'`); output under gpurun_out/, what is worth keeping is copied to profiles/.
+# Every GPU step runs under its own timeout and a step that was killed stops the script (no retries).
+#   checks [tests|bench|prof|all]   smoke + pytest -m gpu / default bench line / rocprofv3 kernel-trace stats of the same command
+#   evidence <tag>                  end-of-round evidence: default bench line, kernel-trace stats and PMC passes of the same command
+#                                   -> gpurun_out/<tag>/ (bench_default.json, kernel_stats.csv, pmc_summary.txt, pmc_traffic_all.json, ...)
+#   kbench <kbench args>            tools/kbench with the arguments given
+#   occ7 | occall | order7 | reg7   kernel experiments with the default library (occupancy padding, traversal order, registered adjacency)
+#   diag7 | reg7d | abl | prio      the same with a diagnostic build (make -C bricklib_amd/csrc EXTRA_HIPFLAGS=-DBRK_DIAG before gpurun)
+set -o pipefail
+mkdir -p gpurun_out
+K=tools/kbench
+killed() { [ "$1" -eq 124 ] || [ "$1" -eq 137 ]; }
+run() { echo "== kbench $*"; timeout -k 10 240 $K "$@"; rc=$?; if killed $rc; then echo killed; exit 1; fi; }
+recipe=${1:-checks}
+
+checks() {
+  what=${1:-all}
+  if [ "$what" = all ] || [ "$what" = tests ]; then
+    timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; rc=$?
+    tail -3 gpurun_out/smoke.log
+    if killed $rc; then echo "smoke killed"; exit 1; fi
+    timeout -k 10 1100 python -m pytest tests -m gpu -q -x --timeout=600 > gpurun_out/pytest_gpu.log 2>&1; rc=$?
+    tail -15 gpurun_out/pytest_gpu.log
+    if killed $rc; then echo "pytest killed"; exit 1; fi
+  fi
+  if [ "$what" = all ] || [ "$what" = bench ]; then
+    timeout -k 10 600 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err; rc=$?
+    cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
+    if killed $rc; then echo "bench killed"; exit 1; fi
+  fi
+  if [ "$what" = all ] || [ "$what" = prof ]; then
+    export TMPDIR=/tmp
+    rm -rf gpurun_out/prof_kt
+    timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_kt.log 2>&1; rc=$?
+    tail -3 gpurun_out/prof_kt.log
+    if killed $rc; then echo "prof killed"; exit 1; fi
+    ls -t $(find gpurun_out/prof_kt -name "*kernel_stats.csv") | head -1 | xargs cat | head -20
+  fi
+}
+
+evidence() {
+  tag=${1:?evidence needs a tag}; d=gpurun_out/$tag; mkdir -p $d
+  timeout -k 10 600 python bench.py > $d/bench_default.json 2> $d/bench_default.err; rc=$?
+  if [ $rc -ne 0 ]; then tail -5 $d/bench_default.err; exit 1; fi
+  python3 - $d <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1] + '/bench_default.json') if l.startswith('{')][-1])
+print('headline', round(d['value'], 1), 'frac', round(d['roofline']['frac'], 4), 'steady', round(d['steady_state']['value'], 1))
+for k, v in d['config3'].items():
+    if isinstance(v, dict): print(' ', k, round(v['kernel_ms'], 4), 'ms frac', round(v['roofline']['frac'], 3), 'err', v.get('max_abs_err_vs_oracle'))
+print('cpu port', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], '| cpu reference', (d.get('cpu_baseline_reference') or {}).get('value'))
+PY
+  checks prof > $d/prof.log 2>&1; tail -12 $d/prof.log
+  cp $(ls -t $(find gpurun_out/prof_kt -name "*kernel_stats.csv") | head -1) $d/kernel_stats.csv
+  bash tools/prof_pmc.sh $tag > $d/pmc.log 2>&1; tail -40 $d/pmc.log
+  cp gpurun_out/pmc_$tag/summary.txt $d/pmc_summary.txt; cp gpurun_out/pmc_$tag/traffic.json $d/pmc_traffic_all.json
+  grep '^{' gpurun_out/prof_kt.log | tail -1 > $d/bench_under_rocprof.json
+  python3 - $d <<'PY'
+import json, csv, sys
+d = json.loads(open(sys.argv[1] + '/bench_under_rocprof.json').read())
+print('bench under rocprof: ms_per_step', d['ms_per_step'], 'kernel_ms', d['roofline'].get('kernel_ms'))
+for r in csv.DictReader(open(sys.argv[1] + '/kernel_stats.csv')):
+    if 'k_s7_wg' in r['Name']: print('rocprof k_s7_wg calls', r['Calls'], 'avg us', float(r['AverageNs']) / 1e3, 'min', float(r['MinNs']) / 1e3)
+PY
+}
+
+case "$recipe" in
+checks) shift; checks "$@" ;;
+evidence) shift; evidence "$@" ;;
+kbench) shift; run "$@" 2>&1 | tee gpurun_out/kbench.log ;;
+*) { case "$recipe" in
+
+occ7)    # 7-point kernel (box and list form) at 24 / 16 / 8 waves per CU (padding with unused LDS)
+  for L in 0 32000 100000; do run -n 512 -s 0 -S -b -v 0 -i 40 -L $L; run -n 512 -s 0 -S -o 8 -v 0,6 -i 40 -L $L; done ;;
+occall)  # every stencil at reduced occupancy
+  for s in 1 3 4 5; do for L in 0 8000 16000 24000; do run -n 512 -s $s -S -o 8 -v 0 -i 20 -L $L; done; done ;;
+diag7)   # diagnostic build (make -C bricklib_amd/csrc EXTRA_HIPFLAGS=-DBRK_DIAG): what each re-read source of the 7-point box kernel costs
+  export TMPDIR=/tmp
+  for D in 0 1 2 3 4 8 13; do
+    run -n 512 -s 0 -S -b -v 0 -i 60 -D $D
+    rm -rf gpurun_out/diag7_pmc_$D
+    timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_EA0_RDREQ_sum --output-format csv -d gpurun_out/diag7_pmc_$D -- tools/kbench -n 512 -s 0 -S -b -v 0 -i 10 -D $D > /dev/null 2>&1
+    python3 - $D <<'PY'
+import csv, glob, sys, collections
+D = sys.argv[1]
+agg = collections.defaultdict(list)
+for f in glob.glob(f"gpurun_out/diag7_pmc_{D}/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "k_s7_wg" in r["Kernel_Name"] and "2" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in sorted(agg.items()):
+    v = v[len(v) // 2:]
+    print(f"   diag {D}: {k} mean over {len(v)} launches = {sum(v) / len(v):.6g}" + (f"  -> reads {2 * sum(v) / len(v) * 1024 / 1e9:.4f} GB" if k == "FETCH_SIZE" else ""))
+PY
+  done ;;
+abl)     # diagnostic build: ablations of the cube kernels (variant code = 1000 + 100 * bits): what does each part of a wave's work cost?
+  for sid in 1 5; do run -n 512 -s $sid -S -o 8 -v 0,1100,1200,1400,1800,2600,4200,1500,1700,4700,7300 -i 30 -r2 3; done ;;
+prio)    # diagnostic build: compute phase (bit 64) / fetch phase (bit 128) of the cube kernels at raised priority
+  for sid in 5 1 7; do run -n 512 -s $sid -S -o 8 -v 0,7400,13800 -i 40 -r2 4; done ;;
+reg7d)   # diagnostic build: registered-adjacency mask path against its bounds (D 16 = mask path without the mask load, D 1 = no adjacency at all)
+  run -n 512 -s 0 -S -b -v 0,100,300,200 -i 100 -r2 6 ;;
+reg7)    # 7-point box kernel with / without brk_adjacency_register
+  for r in 1 2 3; do run -n 512 -s 0 -S -b -v 0 -i 60; run -n 512 -s 0 -S -b -v 0 -i 60 -R; done ;;
+order7)  # 7-point list form: rows per block of the XCD slab order
+  for o in 2 4 8 16; do run -n 512 -s 0 -S -o $o -v 0 -i 60; done ;;
+
+*) echo "unknown recipe $recipe"; exit 2 ;;
+esac; } 2>&1 | tee gpurun_out/r03_$recipe.txt ;;
+esac

@@ -277,8 +277,9 @@ int main(int argc, char **argv) {
     else
       BK(brk_stencil_apply_range(sid, adj_d, st_in, out, step, first, first + nlist, cp, nullptr));
   };
-  // reference output with the generic kernel
-  BK(brk_set_variant(sid, 1));
+  // reference output with the generic kernel (variant 1) where the library was built with VARIANTS=1, else with the default kernel
+  const bool have_variants = brk_set_variant(sid, 1) == BRK_OK;
+  if (!have_variants) BK(brk_set_variant(sid, 0));
   launch(ref_out);
   CK(hipDeviceSynchronize());
 
@@ -329,12 +330,16 @@ int main(int argc, char **argv) {
     for (int vcode : variants) {
       const int v = vcode % 100, mode = vcode / 100;
       if (mode == 1 || mode == 3) BK(brk_adjacency_register(adj_d, nbricks));
-      if (set_diag && mode >= 2) set_diag(mode == 2 ? 1 : 16);
+      if (set_diag && mode >= 2 && mode < 10) set_diag(mode == 2 ? 1 : 16);
+      if (set_diag && mode >= 10) set_diag(mode - 10); // 10xx + 100 * bits: ablation bits of the cube kernels (diagnostic builds)
       struct Undo {
         int mode; const uint32_t *adj; diag_fn2 sd;
         ~Undo() { if (mode == 1 || mode == 3) { (void)hipDeviceSynchronize(); brk_adjacency_release(adj); } if (sd && mode >= 2) sd(0); }
       } undo{mode, adj_d, set_diag};
-      BK(brk_set_variant(sid, v));
+      if (brk_set_variant(sid, v) != BRK_OK) {
+        printf("variant %d  not in this build of libbrk.so (make -C bricklib_amd/csrc VARIANTS=1)\n", vcode);
+        continue;
+      }
       for (int w = 0; w < 3; ++w) launch(st_out);
       CK(hipEventRecord(e0));
       for (int it = 0; it < iters; ++it) launch(st_out);
