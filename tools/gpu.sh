@@ -72,6 +72,54 @@ evidence) shift; evidence "$@" ;;
 kbench) shift; run "$@" 2>&1 | tee gpurun_out/kbench.log ;;
 *) { case "$recipe" in
 
+l1slots) # outstanding L1->L2 read requests per TCP in the brick-copy probe (tools/l1probe): latency sum / (kernel cycles x 256)
+  export TMPDIR=/tmp
+  for l in 0 53000 80000; do
+    rm -rf gpurun_out/l1slots_$l
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/l1slots_$l -- tools/l1probe -w 4 -l $l -i 6 > /dev/null 2>&1
+    python3 - $l <<'PY'
+import csv, glob, sys, collections, re
+l = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"gpurun_out/l1slots_{l}/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"k_probe<([^>]*)>", r["Kernel_Name"])
+        if m: agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, c in sorted(agg.items()):
+    g = lambda n: sum(c[n]) / max(1, len(c[n]))
+    cyc = g("GRBM_GUI_ACTIVE") / 8
+    if g("TCP_TCC_READ_REQ_sum"):
+        print(f"extra LDS {l}: k_probe<{k}> (own, halo, planes/side, waves): {g('TCP_TCC_READ_REQ_sum')/256:.0f} requests per TCP, latency {g('TCP_TCC_READ_REQ_LATENCY_sum')/g('TCP_TCC_READ_REQ_sum'):.0f} clk, "
+              f"kernel {cyc:.0f} clk -> {g('TCP_TCC_READ_REQ_LATENCY_sum')/256/cyc:.1f} requests in flight per TCP")
+PY
+  done ;;
+tapmc)   # how busy is the vector memory path (TA / TCP / TD) in each default kernel?  PMC passes over kbench, one stencil per process
+  export TMPDIR=/tmp
+  for sid in 0 3 4 1 5; do
+    i=0
+    for ctrs in "TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" "TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum" \
+                "TCP_GATE_EN1_sum TCP_GATE_EN2_sum" "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
+                "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TAGRAM0_REQ_sum TCP_TAGRAM1_REQ_sum" "TD_TD_BUSY_sum TD_TC_STALL_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
+      i=$((i + 1)); rm -rf gpurun_out/tapmc_${sid}_$i
+      timeout -k 10 200 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/tapmc_${sid}_$i -- tools/kbench -n 512 -s $sid -S -o 8 -v 0 -i 10 > /dev/null 2>&1
+    done
+    python3 - $sid <<'PY'
+import csv, glob, sys, collections
+sid = sys.argv[1]
+agg = collections.defaultdict(list)
+name = None
+for f in glob.glob(f"gpurun_out/tapmc_{sid}_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if ("k_s7_wg" in k or "k_star_wg" in k or "k_cube_dense" in k):
+            name = k.split("(")[0][-40:]
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+print(f"stencil {sid}: {name}")
+for k, v in sorted(agg.items()):
+    v = v[len(v) // 2:]
+    print(f"   {k:44s} {sum(v) / len(v):.6g}")
+PY
+  done ;;
 occ7)    # 7-point kernel (box and list form) at 24 / 16 / 8 waves per CU (padding with unused LDS)
   for L in 0 32000 100000; do run -n 512 -s 0 -S -b -v 0 -i 40 -L $L; run -n 512 -s 0 -S -o 8 -v 0,6 -i 40 -L $L; done ;;
 occall)  # every stencil at reduced occupancy
