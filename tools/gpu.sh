@@ -36,7 +36,7 @@ checks() {
     timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_kt.log 2>&1; rc=$?
     tail -3 gpurun_out/prof_kt.log
     if killed $rc; then echo "prof killed"; exit 1; fi
-    ls -t $(find gpurun_out/prof_kt -name "*kernel_stats.csv") | head -1 | xargs cat | head -20
+    ls -t $(find gpurun_out/prof_kt -name "*kernel_stats.csv") | head -1 | xargs cat | head -8 | cut -c1-220
   fi
 }
 
