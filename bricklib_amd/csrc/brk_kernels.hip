@@ -311,7 +311,7 @@ extern "C" int brk_set_variant(int id, int v) {
 //   * a replaced list is not freed in place and nothing waits under the mutex: it moves to a retired list and is released by a
 //     later call once hipEventQuery says its last reader has finished (no device-wide synchronisation, no hipSetDevice).
 struct BoxList {
-  uint32_t key[11];
+  uint32_t key[12];
   uint32_t *dev;
   uint32_t n;
   uint64_t stamp;
@@ -344,10 +344,11 @@ void reap_retired_locked() {
 }
 
 // caller holds g_box_mutex
-int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], BoxList **entry) {
+// rows_per_block: j-rows of an XCD slab swept over all k before the next block (the distance between the two uses of a k-face)
+int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], uint32_t rows_per_block, BoxList **entry) {
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
-  const uint32_t key[11] = {(uint32_t)device, base, tot[0], tot[1], tot[2], lo[0], lo[1], lo[2], cnt[0], cnt[1], cnt[2]};
+  const uint32_t key[12] = {(uint32_t)device, base, tot[0], tot[1], tot[2], lo[0], lo[1], lo[2], cnt[0], cnt[1], cnt[2], rows_per_block};
   int victim = 0;
   for (int q = 0; q < kBoxCache; ++q) {
     if (g_box[q].dev && std::memcmp(g_box[q].key, key, sizeof key) == 0) {
@@ -357,7 +358,7 @@ int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], 
     }
     if (g_box[q].stamp < g_box[victim].stamp) victim = q;
   }
-  const uint32_t ni = cnt[0], nj = cnt[1], nk = cnt[2], rowlen = ni % 8 ? ni + 1 : ni, rows_per_block = 8;
+  const uint32_t ni = cnt[0], nj = cnt[1], nk = cnt[2], rowlen = ni % 8 ? ni + 1 : ni;
   auto id_at = [&](uint32_t k, uint32_t j, uint32_t i) { return base + ((lo[2] + k) * tot[1] + (lo[1] + j)) * tot[0] + lo[0] + i; };
   std::vector<std::vector<uint32_t>> part(8);
   const uint32_t jbase = nj / 8, rem = nj % 8;
@@ -550,7 +551,11 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
   // other stencils: the same traversal order as an id list, built once per box geometry and kept on the device
   std::lock_guard<std::mutex> lock(g_box_mutex);
   BoxList *e = nullptr;
-  if (int rc = box_list_locked(base, tot, lo, cnt, &e)) return rc;
+  // Blocks of 8 rows for every stencil.  Measured for the radius-4 star (round 3, interleaved runs on one box): blocks of 4 rows keep
+  // the k-halo lines in the 4-MiB L2 until the brick itself is swept (fabric reads 1.05 -> 0.73 GB, FETCH_SIZE 709 174 KB, traffic
+  // 3.18 -> 2.53 GB per 512^3 sweep) but the sweep takes 0.500-0.508 ms instead of 0.493-0.495: the extra reads are served by the
+  // Infinity Cache and are not what bounds the kernel, the shorter rows-in-flight window is (profiles/r03_d_25pt_rows_per_block.txt).
+  if (int rc = box_list_locked(base, tot, lo, cnt, 8u, &e)) return rc;
   if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s)) return rc;
   HIP_TRY(hipEventRecord(e->last_use, static_cast<hipStream_t>(s)));
   return BRK_OK;
