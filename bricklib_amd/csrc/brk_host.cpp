@@ -65,7 +65,47 @@ const std::vector<uint64_t> &surface_order() {
       make_set({3})};
   return v;
 }
+
+// src/brick-mpi.cpp:54-82 (skin3d_normal): the 27 sections in lexicographic order of (axis 3, axis 2, axis 1) in {-, none, +},
+// the empty set (no surface section: a run separator) in the middle
+std::vector<uint64_t> surface_order_normal() {
+  std::vector<uint64_t> v;
+  const int pick[3] = {-1, 0, +1};
+  for (int c : pick)
+    for (int b : pick)
+      for (int a : pick) {
+        uint64_t s = 0;
+        if (a) s |= dir_bit(a * 1);
+        if (b) s |= dir_bit(b * 2);
+        if (c) s |= dir_bit(c * 3);
+        v.push_back(s);
+      }
+  return v;
+}
+// src/brick-mpi.cpp:84-136 (skin3d_bad): the same 26 sections with an empty set between any two, so that no two sections
+// are ever contiguous for a neighbour (one run per section: 98 runs)
+std::vector<uint64_t> surface_order_bad() {
+  std::vector<uint64_t> v;
+  for (uint64_t s : surface_order_normal())
+    if (s) {
+      if (!v.empty()) v.push_back(0);
+      v.push_back(s);
+    }
+  return v;
+}
 } // namespace
+
+extern "C" int brk_skin3d_order(int which, uint64_t *out, uint32_t *n) {
+  if (!out || !n) return brk_fail(BRK_EINVAL, "brk_skin3d_order: null argument");
+  std::vector<uint64_t> v;
+  if (which == BRK_SKIN3D_GOOD) v = surface_order();
+  else if (which == BRK_SKIN3D_NORMAL) v = surface_order_normal();
+  else if (which == BRK_SKIN3D_BAD) v = surface_order_bad();
+  else return brk_fail(BRK_EINVAL, "brk_skin3d_order: unknown order %d", which);
+  std::copy(v.begin(), v.end(), out);
+  *n = (uint32_t)v.size();
+  return BRK_OK;
+}
 
 // src/brick-mpi.cpp:9-23 -- for axis 1,2,3 in turn choose '+', nothing, '-' (axis 1 varies slowest).
 void brk_dir::neighbors3(std::array<uint64_t, 27> &out) {
@@ -150,8 +190,28 @@ void number_section(brk_decomp &D, uint64_t owner, uint64_t region, uint32_t &ne
 } // namespace
 
 extern "C" int brk_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cells, brk_decomp **out) {
-  if (!dims_cells || !out)
+  return brk_decomp_build_order(dims_cells, ghost_cells, surface_order().data(), (uint32_t)surface_order().size(), out);
+}
+
+// initialize(skinlist) of the reference for ANY order of the surface sections (include/brick-mpi.h:322-460): every one of the 26
+// sections must appear exactly once; empty sets may stand anywhere (they number nothing and end a neighbour's run, :393,:424-446)
+extern "C" int brk_decomp_build_order(const uint32_t dims_cells[3], uint32_t ghost_cells, const uint64_t *order, uint32_t norder,
+                                      brk_decomp **out) {
+  if (!dims_cells || !out || !order)
     return brk_fail(BRK_EINVAL, "brk_decomp_build: null argument");
+  {
+    std::array<uint64_t, 27> all;
+    neighbors3(all);
+    if (norder > BRK_MAX_SKIN) return brk_fail(BRK_EINVAL, "brk_decomp_build: %u surface sections exceed %d", norder, BRK_MAX_SKIN);
+    for (uint64_t want : all) {
+      if (!want) continue;
+      if (std::count(order, order + norder, want) != 1)
+        return brk_fail(BRK_EINVAL, "brk_decomp_build: every one of the 26 surface sections must be listed exactly once");
+    }
+    for (uint32_t q = 0; q < norder; ++q)
+      if (order[q] && std::find(all.begin(), all.end(), order[q]) == all.end())
+        return brk_fail(BRK_EINVAL, "brk_decomp_build: entry %u of the order is not a surface section", q);
+  }
   if (ghost_cells == 0 || ghost_cells % 8)
     return brk_fail(BRK_EINVAL, "brk_decomp_build: ghost depth %u is not a positive multiple of the brick edge 8", ghost_cells);
   for (int a = 0; a < 3; ++a)
@@ -173,7 +233,7 @@ extern "C" int brk_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cel
     return brk_fail(BRK_EINVAL, "brk_decomp_build: %llu bricks do not fit 32-bit ids", (unsigned long long)total);
   }
   D->grid.assign((size_t)total, 0u);
-  D->skinlist = surface_order();
+  D->skinlist.assign(order, order + norder);
 
   uint32_t next = 1;
   number_section(*D, 0, 0, next);
@@ -181,7 +241,7 @@ extern "C" int brk_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cel
   std::vector<uint32_t> sec_start;
   for (uint64_t sec : D->skinlist) {
     sec_start.push_back(next);
-    number_section(*D, 0, sec, next);
+    if (sec) number_section(*D, 0, sec, next); // an empty set numbers nothing (:393)
     D->skin_size.push_back((int64_t)next - (int64_t)sec_start.back());
   }
   sec_start.push_back(next);
@@ -204,7 +264,7 @@ extern "C" int brk_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cel
       run_first = -1;
     };
     for (int l = 0; l < nsec; ++l) {
-      if (contains(D->skinlist[l], toward_us)) {
+      if (D->skinlist[l] && contains(D->skinlist[l], toward_us)) {
         if (run_first < 0) {
           run_first = l;
           run_pos = next;

@@ -93,7 +93,10 @@ int build_runs(const brk_decomp *d, const int ranks[27], int me, int mode, unsig
                            (uint64_t)d->ghost[q].pos * brick_bytes, (uint64_t)d->ghost[q].len * brick_bytes});
   if (mode == BRK_XCHG_DIRECT) {
     // one message per run, the same run order on every rank: pairs match by issue order per peer
+    // (a run can be empty -- a section with no bricks, e.g. an axis exactly two ghost depths wide under skin3d_normal / _bad --
+    //  and then sends nothing: ghost[q].len == skin[q].len on every rank, so both sides skip it)
     for (size_t q = 0; q < nr; ++q) {
+      if (d->ghost[q].len == 0) continue;
       if (remote(src[q]))
         P->msgs.push_back({0, 0, src[q], BRK_SP_STORAGE, (uint64_t)d->ghost[q].pos * brick_bytes, (uint64_t)d->ghost[q].len * brick_bytes});
       if (remote(dst[q]))

@@ -44,12 +44,25 @@ def rank_origin(coo, cart_dims, dom):
     return [((cart_dims[2 - a] - coo[2 - a]) % cart_dims[2 - a]) * dom[a] for a in range(3)]
 
 
-class BrickDecomp:
-    """BrickDecomp<3,8,8,8>(dims, depth) + initialize(skin3d_good) (include/brick-mpi.h:178-460)."""
+SKIN3D = {"good": 0, "normal": 1, "bad": 2}
 
-    def __init__(self, dims, depth=8):
+
+def skin3d(which="good"):
+    """skin3d_good / skin3d_normal / skin3d_bad of src/brick-mpi.cpp:25-136 as BitSet.set values (0 = the empty set)"""
+    out, n = (C.c_uint64 * 64)(), C.c_uint32()
+    check(lib.brk_skin3d_order(SKIN3D[which], out, C.byref(n)))
+    return [int(out[q]) for q in range(n.value)]
+
+
+class BrickDecomp:
+    """BrickDecomp<3,8,8,8>(dims, depth) + initialize(order) (include/brick-mpi.h:178-460); order: "good" (the reference's
+    recommendation and every driver's choice), "normal", "bad", or a list of BitSet.set values."""
+
+    def __init__(self, dims, depth=8, order="good"):
         h = C.c_void_p()
-        check(lib.brk_decomp_build((C.c_uint32 * 3)(*[int(d) for d in dims]), int(depth), C.byref(h)))
+        sl = skin3d(order) if isinstance(order, str) else [int(x) for x in order]
+        check(lib.brk_decomp_build_order((C.c_uint32 * 3)(*[int(d) for d in dims]), int(depth), (C.c_uint64 * len(sl))(*sl), len(sl),
+                                         C.byref(h)))
         self._h = h
         self.dims = [int(d) for d in dims]
         self.depth = int(depth)

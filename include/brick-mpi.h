@@ -6,7 +6,7 @@
 //     group -> unpack, all inside libbrk.so (brk_exchange_*), on the communicator in BrickDecomp::rccl_comm;
 //   * when an MPI implementation is present at compile time and no RCCL communicator has been set: the reference's
 //     run-by-run exchange over MPI (host storages, or device pointers with a GPU-aware MPI as weak/main.cu does).
-// Only the configuration the reference's drivers use is provided: 3 dimensions, 8x8x8 bricks, the skin3d_good section order.
+// Provided: 3 dimensions, 8x8x8 bricks (what the reference's drivers use), any order of the surface sections (skin3d_good / _normal / _bad or a list of one's own).
 #pragma once
 
 #include <ostream>
@@ -98,14 +98,13 @@ public:
   BrickDecomp &operator=(const BrickDecomp &) = delete;
   ~BrickDecomp() { brk_decomp_free(h_); }
 
-  // the reference takes the order of the 26 surface sections here; the library implements skin3d_good
+  // the order of the surface sections (reference :322): skin3d_good (recommended), skin3d_normal, skin3d_bad or any list in
+  // which each of the 26 sections appears once (empty sets allowed as run separators)
   void initialize(const std::vector<BitSet> &order) {
-    if (brk_decomp_build(cells_, depth_, &h_) != BRK_OK) throw std::runtime_error(brk_last_error());
+    std::vector<uint64_t> raw;
+    for (const BitSet &b : order) raw.push_back(b.set);
+    if (brk_decomp_build_order(cells_, depth_, raw.data(), (uint32_t)raw.size(), &h_) != BRK_OK) throw std::runtime_error(brk_last_error());
     const uint32_t ns = brk_decomp_nskin(h_);
-    const uint64_t *sl = brk_decomp_skinlist(h_);
-    if (order.size() != ns) throw std::runtime_error("BrickDecomp::initialize: only skin3d_good is provided");
-    for (uint32_t q = 0; q < ns; ++q)
-      if (order[q].set != sl[q]) throw std::runtime_error("BrickDecomp::initialize: only skin3d_good is provided");
     skinlist = order;
     const int64_t *ss = brk_decomp_skin_size(h_);
     skin_size.assign(ss, ss + ns);
@@ -254,21 +253,30 @@ inline mpi_stats mpi_statistics(double value, MPI_Comm comm) {
 }
 #endif
 
-// the order of the 26 surface sections the reference recommends (src/brick-mpi.cpp:25-52)
+// the three orders of the surface sections the reference ships (src/brick-mpi.cpp:25-136), from the library
+inline std::vector<BitSet> brk_skin3d_list(int which) {
+  uint64_t raw[BRK_MAX_SKIN];
+  uint32_t n = 0;
+  std::vector<BitSet> out;
+  if (brk_skin3d_order(which, raw, &n) == BRK_OK)
+    for (uint32_t q = 0; q < n; ++q) out.emplace_back(raw[q]);
+  return out;
+}
 inline const std::vector<BitSet> &skin3d_good_list() {
-  static const std::vector<BitSet> v = [] {
-    brk_decomp *h = nullptr;
-    const uint32_t c[3] = {16, 16, 16};
-    std::vector<BitSet> out;
-    if (brk_decomp_build(c, 8, &h) == BRK_OK) {
-      for (uint32_t q = 0; q < brk_decomp_nskin(h); ++q) out.emplace_back(brk_decomp_skinlist(h)[q]);
-      brk_decomp_free(h);
-    }
-    return out;
-  }();
+  static const std::vector<BitSet> v = brk_skin3d_list(BRK_SKIN3D_GOOD);
+  return v;
+}
+inline const std::vector<BitSet> &skin3d_normal_list() {
+  static const std::vector<BitSet> v = brk_skin3d_list(BRK_SKIN3D_NORMAL);
+  return v;
+}
+inline const std::vector<BitSet> &skin3d_bad_list() {
+  static const std::vector<BitSet> v = brk_skin3d_list(BRK_SKIN3D_BAD);
   return v;
 }
 #define skin3d_good (skin3d_good_list())
+#define skin3d_normal (skin3d_normal_list())
+#define skin3d_bad (skin3d_bad_list())
 
 // neighbour -> rank on a periodic Cartesian grid with MPI_Cart_rank's row-major rank order (reference populate(),
 // include/brick-mpi.h:730-753, including its orientation: the "+d" neighbour sits at coordinate - 1)

@@ -158,6 +158,15 @@ typedef struct {
   uint32_t skin_st, skin_ed, pos, len, first_pad, last_pad; /* g_region, include/brick-mpi.h:185-193 */
 } brk_region;
 int brk_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cells, brk_decomp **out);
+/* The same for any order of the 26 surface sections (the argument of BrickDecomp::initialize, include/brick-mpi.h:322): `order` lists
+ * BitSet values (brk_allneighbors3 encoding), each section exactly once, empty sets (0) allowed anywhere as run separators.
+ * brk_skin3d_order fills the three orders the reference ships (src/brick-mpi.cpp:25-136; out needs BRK_MAX_SKIN entries). */
+#define BRK_SKIN3D_GOOD 0
+#define BRK_SKIN3D_NORMAL 1
+#define BRK_SKIN3D_BAD 2
+#define BRK_MAX_SKIN 64
+int brk_decomp_build_order(const uint32_t dims_cells[3], uint32_t ghost_cells, const uint64_t *order, uint32_t norder, brk_decomp **out);
+int brk_skin3d_order(int which, uint64_t *out, uint32_t *n);
 void brk_decomp_free(brk_decomp *d);
 uint32_t brk_decomp_nbricks(const brk_decomp *d);           /* incl. dummy brick 0 */
 uint32_t brk_decomp_grid_size(const brk_decomp *d);

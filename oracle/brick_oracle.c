@@ -548,10 +548,10 @@ typedef struct {
   uint32_t nbricks, grid_size;
   uint32_t *grid, *adj;
   int nskin;
-  uint64_t skinlist[32];
-  long skin_size[32];
+  uint64_t skinlist[64];
+  long skin_size[64];
   int nruns;
-  orc_region ghost[80], skin[80];
+  orc_region ghost[128], skin[128];
 } orc_decomp;
 
 /* brick-mpi.h:218-239 : number the bricks of `region` of the domain displaced by `ref` */
@@ -592,7 +592,41 @@ static void dec_populate(orc_decomp *D, uint64_t owner, uint64_t region, uint32_
 
 static int subset(uint64_t a, uint64_t b) { return (a & b) == a; }
 
+/* skin3d_normal / skin3d_bad (ref: src/brick-mpi.cpp:54-136): lexicographic order of (axis 3, axis 2, axis 1) in {-, none, +}
+ * with the empty set in the middle / the same 26 sections with an empty set between any two.  which: 0 good, 1 normal, 2 bad */
+int orc_skin3d(int which, uint64_t out[64]) {
+  if (which == 0) {
+    orc_skin3d_good(out);
+    return 26;
+  }
+  int n = 0;
+  const int pick[3] = {-1, 0, 1};
+  for (int c = 0; c < 3; ++c)
+    for (int b = 0; b < 3; ++b)
+      for (int a = 0; a < 3; ++a) {
+        int e[3], m = 0;
+        if (pick[a]) e[m++] = pick[a] * 1;
+        if (pick[b]) e[m++] = pick[b] * 2;
+        if (pick[c]) e[m++] = pick[c] * 3;
+        const uint64_t set = orc_bitset_of(e, m);
+        if (which == 1) {
+          out[n++] = set;
+        } else if (set) {
+          if (n) out[n++] = 0;
+          out[n++] = set;
+        }
+      }
+  return n;
+}
+
+orc_decomp *orc_decomp_build_order(const uint32_t dims_cells[3], uint32_t ghost_cells, const uint64_t *order, int norder);
 orc_decomp *orc_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cells) {
+  uint64_t good[64];
+  orc_skin3d_good(good);
+  return orc_decomp_build_order(dims_cells, ghost_cells, good, 26);
+}
+
+orc_decomp *orc_decomp_build_order(const uint32_t dims_cells[3], uint32_t ghost_cells, const uint64_t *order, int norder) {
   orc_decomp *D = (orc_decomp *)calloc(1, sizeof(orc_decomp));
   uint32_t gs = 1;
   for (int d = 0; d < 3; ++d) {
@@ -604,11 +638,11 @@ orc_decomp *orc_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cells)
   }
   D->grid_size = gs;
   D->grid = (uint32_t *)malloc(sizeof(uint32_t) * gs);
-  orc_skin3d_good(D->skinlist);
-  D->nskin = 26;
+  for (int l = 0; l < norder; ++l) D->skinlist[l] = order[l];
+  D->nskin = norder;
 
   uint32_t pos = 1; /* factor == 1: id 0 is the dummy brick (brick-mpi.h:353) */
-  uint32_t st_pos[40];
+  uint32_t st_pos[72];
   int nst = 0;
 
   dec_populate(D, 0, 0, &pos); /* inner region */

@@ -78,6 +78,9 @@ class Oracle:
         L.orc_skin3d_good.argtypes = [_u64p]
         L.orc_decomp_build.restype = C.c_void_p
         L.orc_decomp_build.argtypes = [C.c_uint32 * 3, C.c_uint32]
+        L.orc_decomp_build_order.restype = C.c_void_p
+        L.orc_decomp_build_order.argtypes = [C.c_uint32 * 3, C.c_uint32, _u64p, C.c_int]
+        L.orc_skin3d.argtypes = [C.c_int, _u64p]
         L.orc_decomp_free.argtypes = [C.c_void_p]
         L.orc_decomp_info.argtypes = [C.c_void_p, _u32p]
         L.orc_decomp_grid.argtypes = [C.c_void_p, _u32p]
@@ -182,8 +185,17 @@ class Oracle:
         self.L.orc_skin3d_good(out)
         return out
 
-    def decomp(self, dims_cells, ghost_cells=8):
-        return _Decomp(self.L, "orc", self.L.orc_decomp_build(_u3(dims_cells), ghost_cells))
+    def decomp(self, dims_cells, ghost_cells=8, order="good"):
+        """order: "good" (skin3d_good), "normal", "bad" (src/brick-mpi.cpp:25-136) or an array of BitSet.set values"""
+        if isinstance(order, str):
+            order = self.skin3d(order)
+        order = np.ascontiguousarray(order, dtype=np.uint64)
+        return _Decomp(self.L, "orc", self.L.orc_decomp_build_order(_u3(dims_cells), ghost_cells, order, order.size))
+
+    def skin3d(self, which="good"):
+        out = np.zeros(64, dtype=np.uint64)
+        n = self.L.orc_skin3d({"good": 0, "normal": 1, "bad": 2}[which], out)
+        return out[:n].copy()
 
     def populate_rank_map(self, cart_dims, coo):
         out = np.empty(27, dtype=np.int32)
@@ -271,6 +283,10 @@ class Ref:
         L.ref_skin3d_good.argtypes = [_u64p]
         L.ref_decomp_build.restype = C.c_void_p
         L.ref_decomp_build.argtypes = [C.c_uint32 * 3, C.c_uint32]
+        if hasattr(L, "ref_decomp_build_order"):
+            L.ref_decomp_build_order.restype = C.c_void_p
+            L.ref_decomp_build_order.argtypes = [C.c_uint32 * 3, C.c_uint32, C.c_int]
+            L.ref_skin3d.argtypes = [C.c_int, _u64p]
         L.ref_decomp_free.argtypes = [C.c_void_p]
         L.ref_decomp_info.argtypes = [C.c_void_p, _u32p]
         L.ref_decomp_grid.argtypes = [C.c_void_p, _u32p]
@@ -342,8 +358,16 @@ class Ref:
         n = self.L.ref_skin3d_good(out)
         return out[:n].copy()
 
-    def decomp(self, dims_cells, ghost_cells=8):
-        return _Decomp(self.L, "ref", self.L.ref_decomp_build(_u3(dims_cells), ghost_cells))
+    def decomp(self, dims_cells, ghost_cells=8, order="good"):
+        which = {"good": 0, "normal": 1, "bad": 2}[order]
+        if which == 0:
+            return _Decomp(self.L, "ref", self.L.ref_decomp_build(_u3(dims_cells), ghost_cells))
+        return _Decomp(self.L, "ref", self.L.ref_decomp_build_order(_u3(dims_cells), ghost_cells, which))
+
+    def skin3d(self, which="good"):
+        out = np.zeros(64, dtype=np.uint64)
+        n = self.L.ref_skin3d({"good": 0, "normal": 1, "bad": 2}[which], out)
+        return out[:n].copy()
 
     def zmort_get(self, zid, d, dim=3):
         return int(self.L.ref_zmort_get(zid, dim, d))

@@ -175,10 +175,18 @@ struct RefDecomp {
   std::vector<unsigned> tdims;
 };
 
-void *ref_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cells) {
+// the reference's three section orders (src/brick-mpi.cpp:25-136): which = 0 good, 1 normal, 2 bad
+int ref_skin3d(int which, uint64_t *out) {
+  const std::vector<BitSet> &v = which == 1 ? skin3d_normal : (which == 2 ? skin3d_bad : skin3d_good);
+  for (size_t q = 0; q < v.size(); ++q) out[q] = v[q].set;
+  return (int)v.size();
+}
+void *ref_decomp_build_order(const uint32_t dims_cells[3], uint32_t ghost_cells, int which);
+void *ref_decomp_build(const uint32_t dims_cells[3], uint32_t ghost_cells) { return ref_decomp_build_order(dims_cells, ghost_cells, 0); }
+void *ref_decomp_build_order(const uint32_t dims_cells[3], uint32_t ghost_cells, int which) {
   auto r = new RefDecomp;
   r->d = new Decomp({dims_cells[0], dims_cells[1], dims_cells[2]}, ghost_cells);
-  r->d->initialize(skin3d_good);
+  r->d->initialize(which == 1 ? skin3d_normal : (which == 2 ? skin3d_bad : skin3d_good));
   for (int a = 0; a < 3; ++a)
     r->tdims.push_back((dims_cells[a] + 2 * ghost_cells) / 8);
   return r;

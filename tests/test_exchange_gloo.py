@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, dom, q, mode):
+def _worker(rank, world, port, dom, q, mode, order="good"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -21,7 +21,7 @@ def _worker(rank, world, port, dom, q, mode):
         import bricklib_amd as bl
         from bricklib_amd.decomp import Exchanger, rank_to_coo
         cart = bl.dims_create(world)
-        d = bl.BrickDecomp(dom)
+        d = bl.BrickDecomp(dom, order=order)
         bl.populate(d, cart, rank_to_coo(rank, cart))
         st = bl.BrickStorage(torch.zeros(d.nbricks * 512, dtype=torch.float64), d.nbricks, 512)
         # every element encodes (rank, brick, element) so a misrouted run is caught exactly
@@ -43,14 +43,16 @@ def _worker(rank, world, port, dom, q, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "direct"), (4, "direct"), (2, "packed"), (4, "packed"), (8, "packed"), (8, "direct"), (2, "shift"),
-                                        (4, "shift"), (8, "shift"), (3, "shift"), (3, "packed"), (6, "direct")])
-def test_exchange_two_ranks_gloo(oracle, world, mode):
+@pytest.mark.parametrize("world,mode,order", [(2, "direct", "good"), (4, "direct", "good"), (2, "packed", "good"), (4, "packed", "good"), (8, "packed", "good"),
+                                              (8, "direct", "good"), (2, "shift", "good"), (4, "shift", "good"), (8, "shift", "good"), (3, "shift", "good"),
+                                              (3, "packed", "good"), (6, "direct", "good"),
+                                              (4, "packed", "bad"), (2, "direct", "normal"), (4, "shift", "bad")])   # the reference's other section orders
+def test_exchange_two_ranks_gloo(oracle, world, mode, order):
     dom = (32, 16, 24)
-    port = 29500 + (os.getpid() % 2000) + world + {"direct": 0, "packed": 10, "shift": 20}[mode]
+    port = 29500 + (os.getpid() % 2000) + world + {"direct": 0, "packed": 10, "shift": 20}[mode] + {"good": 0, "normal": 40, "bad": 50}[order]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dom, q, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dom, q, mode, order)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -63,7 +65,7 @@ def test_exchange_two_ranks_gloo(oracle, world, mode):
     # oracle: same initial storages, exchange in one address space
     import bricklib_amd as bl
     from bricklib_amd.decomp import rank_to_coo
-    od = oracle.decomp(dom)
+    od = oracle.decomp(dom, order=order)
     cart = bl.dims_create(world)
     storages = [np.arange(od.nbricks * 512, dtype=np.float64) + r * 1e9 for r in range(world)]
     maps = [oracle.populate_rank_map(cart, rank_to_coo(r, cart)) for r in range(world)]

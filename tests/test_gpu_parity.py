@@ -169,6 +169,13 @@ def test_weak_cycle_virtual_ranks(oracle, dev, name, nranks):
     _weak_virtual(oracle, dev, name, nranks, (16, 16, 16), "lists" if nranks != 2 else "ranges")
 
 
+@pytest.mark.parametrize("order,name,nranks,schedule", [("normal", "mpi7pt", 2, "lists"), ("bad", "mpi13pt", 8, "ranges"), ("bad", "mpi7pt_x2", 4, "deep")])
+def test_weak_cycle_other_section_orders(oracle, dev, order, name, nranks, schedule):
+    """the weak cycle on decompositions laid out in the reference's other section orders (skin3d_normal: 62 runs, skin3d_bad: 98
+    runs, src/brick-mpi.cpp:54-136): brick numbering, run tables, sweep lists and exchange all follow the order given to initialize"""
+    _weak_virtual(oracle, dev, name, nranks, (40, 32, 48) if schedule == "deep" else (16, 16, 16), schedule, order=order)
+
+
 @pytest.mark.parametrize("schedule,nranks", [("lists", 1), ("lists", 8), ("ranges", 2), ("deep", 4)])
 def test_weak_cycle_fused_double_sweeps(oracle, dev, schedule, nranks):
     """the weak cycle with BRK_MPI7_X2 (4 fused passes = the 8 sweeps of mpi7pt between two exchanges) against the global
@@ -194,10 +201,10 @@ def test_weak_cycle_vs_reference_run_under_mpi(oracle, golden, dev, name, st, nr
                   ref={r: z[f"out_{st}_{nranks}_{r}"] for r in range(nranks)})
 
 
-def _weak_virtual(oracle, dev, name, nranks, dom, schedule, seed=11, ncycles=2, ref=None):
+def _weak_virtual(oracle, dev, name, nranks, dom, schedule, seed=11, ncycles=2, ref=None, order="good"):
     cart = bl.dims_create(nranks)
     gdims = [cart[2 - a] * dom[a] for a in range(3)]
-    d = bl.BrickDecomp(dom)
+    d = bl.BrickDecomp(dom, order=order)
     info = d.getBrickInfo(dev)
     gdev = grid_to_device(d.grid.reshape(-1), dev)
     ext = tuple(x + 16 for x in dom)
@@ -211,7 +218,7 @@ def _weak_virtual(oracle, dev, name, nranks, dom, schedule, seed=11, ncycles=2, 
         stA[r], stB[r] = info.allocate(512, dev), info.allocate(512, dev)
         bl.copyToBrick(ext, (0,) * 3, (0,) * 3, torch.from_numpy(arr).to(dev), gdev, bl.Brick(info, stA[r], 0))
     links, remote = local_links(d, stA, maps, set(range(nranks)))
-    assert not remote and len(links) == 42 * nranks
+    assert not remote and len(links) == {"good": 42, "normal": 62, "bad": 98}[order] * nranks
     table = LinkTable(links, dev)
     S = bl.stencil_iters(name)
     from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep

@@ -50,6 +50,30 @@ def test_decomp_golden(golden, dims):
     assert (d.runs_table("ghost") == z["ghost"]).all() and (d.runs_table("skin") == z["skin"]).all()
 
 
+@pytest.mark.parametrize("order", ["normal", "bad"])
+@pytest.mark.parametrize("dims", [(16, 16, 16), (24, 32, 40), (64, 64, 64)])
+def test_decomp_golden_other_section_orders(golden, dims, order):
+    """brk_decomp_build_order with skin3d_normal / skin3d_bad against the reference's own tables; a list that misses a section,
+    repeats one or names something that is not a section is refused"""
+    z = golden("decomp_%s_%dx%dx%d" % ((order,) + dims))
+    assert (np.array(bl.decomp.skin3d(order), dtype=np.uint64) == z["skinlist"]).all()
+    d = bl.BrickDecomp(dims, 8, order=order)
+    assert d.sep_pos == [int(x) for x in z["sep_pos"]] and d.nbricks == int(z["nbricks"][0])
+    assert (d.grid.reshape(-1) == z["grid"]).all()
+    assert (d.adj[1:] == z["adj_from1"]).all() and (d.adj[0] == 0).all()
+    assert (np.array(d.skin_size) == z["skin_size"]).all()
+    assert (d.runs_table("ghost") == z["ghost"]).all() and (d.runs_table("skin") == z["skin"]).all()
+    good = bl.decomp.skin3d("good")
+    for broken in (good[:-1], good + [good[0]], good[:-1] + [good[-1] | good[0] | (1 << 40)]):
+        with pytest.raises(bl.BrkError):
+            bl.BrickDecomp(dims, 8, order=broken)
+    # a list of one's own: skin3d_good reversed, with separators sprinkled in
+    mine = list(reversed(good))
+    mine.insert(5, 0)
+    d2 = bl.BrickDecomp(dims, 8, order=mine)
+    assert d2.nbricks == int(z["nbricks"][0]) and sorted(np.unique(d2.grid).tolist()) == list(range(1, d2.nbricks))
+
+
 def test_decomp_512_matches_survey_appendix_a(oracle):
     d = bl.BrickDecomp((512, 512, 512), 8)
     o = oracle.decomp((512, 512, 512))
