@@ -220,6 +220,29 @@ public:
     }
     MPI_Waitall((int)req.size(), req.data(), MPI_STATUSES_IGNORE);
   }
+
+  // one-sided form (reference include/brick-mpi.h:688-712, marked "don't use" there): between two fences every ghost run is
+  // fetched with MPI_Get from the same-index skin run of the rank behind it; `win` exposes the peer's whole storage in bytes.
+  // Host storages (or device pointers under a GPU-aware MPI); wait / call times go to the reference's accumulators.
+  void exchange(BrickStorage bStorage, MPI_Win &win) {
+    double st = MPI_Wtime(), ed;
+    MPI_Win_fence(0, win);
+    ed = MPI_Wtime();
+    waittime += ed - st;
+    st = ed;
+    bElem *dat = bStorage.dat.get();
+    const size_t bytes_per_brick = bStorage.step * sizeof(bElem);
+    for (size_t q = 0; q < ghost.size(); ++q) {
+      const int len = (int)(ghost[q].len * bytes_per_brick);
+      MPI_Get(dat + (size_t)ghost[q].pos * bStorage.step, len, MPI_CHAR, rank_map[ghost[q].neighbor.set],
+              (MPI_Aint)((size_t)skin[q].pos * bytes_per_brick), len, MPI_CHAR, win);
+    }
+    ed = MPI_Wtime();
+    calltime += ed - st;
+    st = ed;
+    MPI_Win_fence(0, win);
+    waittime += MPI_Wtime() - st;
+  }
 #endif
 
 private:

@@ -320,3 +320,28 @@ void f(MPI_Comm cart, BrickStorage &st) {
 }
 ''')
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-I", inc, str(src)])
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("np_,order", [(2, "good"), (8, "good"), (4, "bad"), (3, "normal")])
+def test_brick_mpi_header_host_exchanges_under_mpiexec(tmp_path, np_, order):
+    """the host-side exchanges of include/brick-mpi.h RUN under a real MPI launcher (conda MPICH in this image): periodic cart grid,
+    populate(cart, ...), bDecomp.exchange(bStorage) (Isend/Irecv per run, reference include/brick-mpi.h:466-495) and
+    bDecomp.exchange(bStorage, win) (MPI_Get between fences, :688-712), in three section orders; every ghost element is checked
+    against the (rank, brick, element) its peer must have sent (tests/probe_mpi_exchange.cpp)."""
+    import shutil
+    mpiexec = shutil.which("mpiexec") or ("/opt/conda/bin/mpiexec" if os.path.exists("/opt/conda/bin/mpiexec") else None)
+    if mpiexec is None or not os.path.exists("/opt/conda/include/mpi.h") or not os.path.exists("/opt/conda/lib/libmpi.so"):
+        pytest.skip("no MPI implementation here")
+    csrc = os.path.join(ROOT, "bricklib_amd", "csrc")
+    exe = tmp_path / "mpi_xchg"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-DMPICH_SKIP_MPICXX", "-I", os.path.join(ROOT, "include"), "-idirafter", "/opt/conda/include",
+                           os.path.join(ROOT, "tests", "probe_mpi_exchange.cpp"), "-o", str(exe), "-L", csrc, "-lbrk", "/opt/conda/lib/libmpi.so",
+                           "-Wl,-rpath," + csrc])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([mpiexec, "-np", str(np_), str(exe), order], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, env=env)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out
+    assert out.count("ghosts match") == 2 and "MISMATCH" not in out, out
+    assert ("%d runs" % {"good": 42, "normal": 62, "bad": 98}[order]) in out, out
