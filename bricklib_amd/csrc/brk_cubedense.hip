@@ -183,7 +183,7 @@ __device__ __forceinline__ bool linked(uint32_t rl, uint32_t rr, int lane) {
 template <int KIND, int NW, int OCC, int PIPE = 1>
 __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
-    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf, int diag) {
+    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf, int diag, const uint32_t *__restrict__ linkmask) {
   constexpr int R = CubeTraits<KIND>::R;
   using TL = DenseTile<KIND>;
   using X = DX<KIND>;
@@ -254,8 +254,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     // below (links, face addresses) waits for the rows -- behind the 4 KiB of the brick that wait is a full HBM round trip
     // (in-kernel stamps: 8500 of a wave's 15000 cycles went by before the face loads were issued)
     const uint32_t arow = adj[(size_t)b * 27 + l27]; // lanes 0..26: the adjacency row
+    // registered adjacency table (brk_adjacency_register): two bits per brick say whether it is linked to its -i / +i adjacency
+    // neighbour (k_link_mask, brk_kernels.hip), so the rows of the list neighbours are not read -- measured with them ablated
+    // (profiles/r03_b_cube_kernel_ablations.txt): 3.7 % (27-point) and 4.4 % (125-point) of the sweep
+    uint32_t lmw_l = 0, lmw_r = 0;
+    if (linkmask) {
+      const uint32_t *lw = linkmask + 4 * (size_t)(b >> 6) + ((b >> 4) & 2u);
+      lmw_l = lw[0], lmw_r = lw[1];
+    }
     uint32_t prow = 0, nrow = 0;
-    if (!DG(8)) {
+    if (!DG(8) && !linkmask) {
       prow = adj[(size_t)(b_prev != BRK_LIST_SKIP ? b_prev : b) * 27 + l27];
       nrow = adj[(size_t)(b_next != BRK_LIST_SKIP ? b_next : b) * 27 + l27];
     }
@@ -273,6 +281,9 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     }
     if (DG(8)) {
       link_l = b_prev != BRK_LIST_SKIP, link_r = b_next != BRK_LIST_SKIP;
+    } else if (linkmask) {
+      link_l = b_prev != BRK_LIST_SKIP && __builtin_amdgcn_readlane(arow, adj_slot(0, 0, -1)) == b_prev && ((lmw_l >> (b & 31u)) & 1u);
+      link_r = b_next != BRK_LIST_SKIP && __builtin_amdgcn_readlane(arow, adj_slot(0, 0, 1)) == b_next && ((lmw_r >> (b & 31u)) & 1u);
     } else {
       link_l = b_prev != BRK_LIST_SKIP && linked(prow, arow, lane);
       link_r = b_next != BRK_LIST_SKIP && linked(arow, nrow, lane);
@@ -500,11 +511,11 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 // static accumulators and one read burst per plane, 9 = the same with the rolled loop over a ring, 6 = NW 4 and 7 = NW 8 with the
 // software-pipelined rolled loop (2 waves/SIMD)
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
+                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *linkmask) {
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8;
   const bool x2 = stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2;
 #define BRK_CD(KIND, NW, OCC, PIPE, WGS, LDS) \
-  hipLaunchKernelGGL((k_cube_dense<KIND, NW, OCC, PIPE>), dim3(WGS), dim3(64 * NW), LDS, st, adj, in, out, step, ids, first, n, cf, g_diag)
+  hipLaunchKernelGGL((k_cube_dense<KIND, NW, OCC, PIPE>), dim3(WGS), dim3(64 * NW), LDS, st, adj, in, out, step, ids, first, n, cf, g_diag, linkmask)
 #ifdef BRK_VARIANTS
   const uint32_t wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
   bool done = true;

@@ -52,7 +52,7 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
 // 27-/125-point kernels: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip), and the earlier padded
 // tiles with shared i-halos (brk_cubewg.hip)
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
+                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *linkmask);
 int launch_cube_wg(int stencil_id, int nw, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 

@@ -210,6 +210,9 @@ int make_coeffs(int id, const double *host, Coeffs &cf) {
   return BRK_OK;
 }
 
+// registered adjacency tables (defined further down): per brick, is it linked to its -i / +i neighbour (see k_link_mask)?
+int link_mask(const uint32_t *adj, hipStream_t st, const uint32_t **out);
+
 int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const double *coeff_host, brk_stream s) {
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
@@ -223,16 +226,19 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
   hipStream_t st = static_cast<hipStream_t>(s);
+  const uint32_t *lmask = nullptr; // cube kernels over a registered table: the rows of the list neighbours need not be read
+  if (id == BRK_27PT_COEFF || id == BRK_MPI125 || id == BRK_MPI7_X2 || id == BRK_7PT_X2)
+    if (int rc = link_mask(adj, st, &lmask)) return rc;
   // default kernels: 7-point family in brk_star7.hip, 13-/25-point in brk_starwg.hip, 27-/125-point and the fused double
   // 7-point sweep in brk_cubedense.hip.  Builds with -DBRK_VARIANTS also carry the earlier generations (brk_set_variant).
 #ifdef BRK_VARIANTS
   if ((id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) && var != 1)
     return launch_star7(id, var == 0 ? kDefaultStar7Variant : var, adj, in, out, step, ids, first, n, cf, st);
   if ((id == BRK_MPI13 || id == BRK_MPI25) && var != 1) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st);
-  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st);
+  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st, lmask);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = var;
-    if (v == 0 || (v >= 5 && v <= 14)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st);
+    if (v == 0 || (v >= 5 && v <= 14)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st, lmask);
     if ((id == BRK_27PT_COEFF && v == 2) || (id == BRK_MPI125 && (v == 2 || v == 4 || v == 8)))
       return launch_cube_wg(id, id == BRK_MPI125 ? v : 8, adj, in, out, step, ids, first, n, cf, st);
   }
@@ -258,7 +264,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   (void)var;
   if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) return launch_star7(id, kDefaultStar7Variant, adj, in, out, step, ids, first, n, cf, st);
   if (id == BRK_MPI13 || id == BRK_MPI25) return launch_star_wg(id, 0, adj, in, out, step, ids, first, n, cf, st);
-  return launch_cube_dense(id, 0, adj, in, out, step, ids, first, n, cf, st);
+  return launch_cube_dense(id, 0, adj, in, out, step, ids, first, n, cf, st, lmask);
 #endif
 }
 
@@ -424,11 +430,39 @@ __global__ void k_regular_mask(const uint32_t *__restrict__ adj, uint32_t nbrick
   }
 }
 
+// Two bits per brick b of a registered table, words 2(b/32) and 2(b/32)+1: is b LINKED to its -i neighbour l = adj[b](0,0,-1) / to
+// its +i neighbour r = adj[b](0,0,+1) in the sense of the cube kernels (brk_cubedense.hip): the two bricks see the same world across
+// their common i-face -- right(dk,dj,-1) == left(dk,dj,0) and right(dk,dj,0) == left(dk,dj,+1) for all nine (dk,dj), which includes
+// right.im == left and left.ip == right.  A wave whose list neighbour IS that adjacency neighbour then shares halo columns with it
+// through LDS without reading the neighbour's adjacency row.
+__global__ void k_link_mask(const uint32_t *__restrict__ adj, uint32_t nbricks, uint32_t *__restrict__ mask) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  bool okl = false, okr = false;
+  if (b < nbricks) {
+    const uint32_t *row = adj + (size_t)b * 27;
+    auto linked_pair = [&](const uint32_t *left, const uint32_t *right) {
+      bool ok = true;
+      for (int q = 0; q < 27; ++q)
+        if (q % 3 != 2) ok = ok && right[q] == left[q + 1];
+      return ok;
+    };
+    const uint32_t l = row[adj_slot(0, 0, -1)], r = row[adj_slot(0, 0, 1)];
+    okl = l < nbricks && linked_pair(adj + (size_t)l * 27, row);
+    okr = r < nbricks && linked_pair(row, adj + (size_t)r * 27);
+  }
+  const unsigned long long ml = __ballot(okl), mr = __ballot(okr);
+  if ((threadIdx.x & 63) == 0) { // bricks 64q .. 64q+63: words 4q (left, low half), 4q+1 (right, low), 4q+2 (left, high), 4q+3 (right, high)
+    uint32_t *w = mask + 4 * (size_t)(b >> 6);
+    w[0] = (uint32_t)ml, w[1] = (uint32_t)mr, w[2] = (uint32_t)(ml >> 32), w[3] = (uint32_t)(mr >> 32);
+  }
+}
+
 struct AdjEntry {
   const uint32_t *adj;
   uint32_t nbricks;
   int device;
   std::vector<std::pair<std::pair<uint32_t, uint32_t>, uint32_t *>> masks; // (s1, s2) -> device bit mask
+  uint32_t *linkmask = nullptr;                                             // k_link_mask, built on first use
 };
 std::mutex g_adj_mutex;
 std::vector<AdjEntry> g_adj;
@@ -464,6 +498,32 @@ int regular_mask(const uint32_t *adj, uint32_t s1, uint32_t s2, hipStream_t st, 
   }
   return BRK_OK;
 }
+
+int link_mask(const uint32_t *adj, hipStream_t st, const uint32_t **out) {
+  *out = nullptr;
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  for (AdjEntry &e : g_adj) {
+    if (e.adj != adj) continue;
+    if (!e.linkmask) {
+      int device = 0;
+      HIP_TRY(hipGetDevice(&device));
+      if (device != e.device) return brk_fail(BRK_EINVAL, "adjacency table registered on device %d used on device %d", e.device, device);
+      uint32_t *mask = nullptr;
+      HIP_TRY(hipMalloc(&mask, (size_t)((e.nbricks + 255) / 256) * 16 * sizeof(uint32_t)));
+      hipLaunchKernelGGL(k_link_mask, dim3((e.nbricks + 255) / 256), dim3(256), 0, st, adj, e.nbricks, mask);
+      hipError_t r = hipGetLastError();
+      if (r == hipSuccess) r = hipStreamSynchronize(st); // the first call for a table is synchronous
+      if (r != hipSuccess) {
+        (void)hipFree(mask);
+        HIP_TRY(r);
+      }
+      e.linkmask = mask;
+    }
+    *out = e.linkmask;
+    return BRK_OK;
+  }
+  return BRK_OK;
+}
 } // namespace
 
 extern "C" int brk_adjacency_register(const uint32_t *adj_dev, uint32_t nbricks) {
@@ -473,7 +533,7 @@ extern "C" int brk_adjacency_register(const uint32_t *adj_dev, uint32_t nbricks)
   std::lock_guard<std::mutex> lock(g_adj_mutex);
   for (const AdjEntry &e : g_adj)
     if (e.adj == adj_dev) return brk_fail(BRK_EINVAL, "brk_adjacency_register: table %p is registered already", (const void *)adj_dev);
-  g_adj.push_back(AdjEntry{adj_dev, nbricks, device, {}});
+  g_adj.push_back(AdjEntry{adj_dev, nbricks, device, {}, nullptr});
   return BRK_OK;
 }
 
@@ -482,6 +542,7 @@ extern "C" int brk_adjacency_release(const uint32_t *adj_dev) {
   for (size_t q = 0; q < g_adj.size(); ++q)
     if (g_adj[q].adj == adj_dev) {
       for (auto &m : g_adj[q].masks) (void)hipFree(m.second); // hipFree waits for the kernels that still read it
+      if (g_adj[q].linkmask) (void)hipFree(g_adj[q].linkmask);
       g_adj.erase(g_adj.begin() + q);
       return BRK_OK;
     }

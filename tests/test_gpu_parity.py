@@ -1192,6 +1192,20 @@ def test_registered_adjacency_box_form_is_bit_identical(oracle, dev):
                 outs.append(stB.dat.clone())
         assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3]), case
         assert outs[0].abs().max().item() > 0
+    # list form of the cube kernels: a registered table replaces the adjacency rows of the list neighbours by two bits per brick
+    # (linked to the -i / +i neighbour); tiled, lexicographic, ragged and shuffled lists, also over the wrapped table above
+    ids_all = np.ascontiguousarray(grid.reshape(shape[2], shape[1], shape[0])[1:-1, 1:-1, 1:-1]).reshape(-1)
+    from bricklib_amd.order import tiled
+    lists = [tiled(grid.reshape(shape[2], shape[1], shape[0])[1:-1, 1:-1, 1:-1]), ids_all, ids_all[3:-5:2].copy(), rng.permutation(ids_all).astype(np.uint32)]
+    for name in ("27pt", "mpi125pt", "mpi7pt_x2"):
+        for ids in lists:
+            outs = []
+            for info in (bl.BrickInfo(raw), bl.BrickInfo(adj, dev)):
+                stB = bl.BrickStorage.allocate(nbricks, 512, dev)
+                bl.apply_stencil(name, bl.Brick(info, stA, 0), bl.Brick(info, stB, 0), ids=grid_to_device(ids, dev), coeff=oracle.coeffs(129, 1) if name == "27pt" else None)
+                outs.append(stB.dat.clone())
+            assert torch.equal(outs[0], outs[1]), (name, ids.size)
+            assert outs[0].abs().max().item() > 0
     # the promise is per table: duplicate registration and unknown release are errors; release, rewrite, register again
     t = grid_to_device(adj.reshape(-1), dev)
     check(lib.brk_adjacency_register(C.c_void_p(t.data_ptr()), nbricks))
