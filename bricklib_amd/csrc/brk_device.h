@@ -39,15 +39,15 @@ __device__ __forceinline__ gcptr sbase(const double *p) {
 // Launchers of the specialised 7-point kernels (brk_star7.hip).  variant: 2 = one brick per wave, every face gathered;
 // 5 / 6 = workgroups of 8 / 4 waves sharing i-faces through LDS.
 int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step,
-                 const uint32_t *ids, uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
+                 const uint32_t *ids, uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *faces);
 
 int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, double *out, size_t step, uint32_t base,
                      const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const Coeffs &cf, hipStream_t st,
-                     const uint32_t *regmask);
+                     const uint32_t *regmask, const uint32_t *faces);
 
 // 13-/25-point kernels with workgroup-shared i-halos (brk_starwg.hip)
 int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                   uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
+                   uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *faces);
 
 // 27-/125-point kernels: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip), and the earlier padded
 // tiles with shared i-halos (brk_cubewg.hip)

@@ -212,6 +212,8 @@ int make_coeffs(int id, const double *host, Coeffs &cf) {
 
 // registered adjacency tables (defined further down): per brick, is it linked to its -i / +i neighbour (see k_link_mask)?
 int link_mask(const uint32_t *adj, hipStream_t st, const uint32_t **out);
+// ... and the six face neighbours of every brick as one aligned 32-byte row (see k_face_table)
+int face_table(const uint32_t *adj, hipStream_t st, const uint32_t **out);
 
 int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const double *coeff_host, brk_stream s) {
@@ -226,15 +228,18 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
   hipStream_t st = static_cast<hipStream_t>(s);
-  const uint32_t *lmask = nullptr; // cube kernels over a registered table: the rows of the list neighbours need not be read
-  if (id == BRK_27PT_COEFF || id == BRK_MPI125 || id == BRK_MPI7_X2 || id == BRK_7PT_X2)
-    if (int rc = link_mask(adj, st, &lmask)) return rc;
+  const uint32_t *lmask = nullptr, *faces = nullptr;
+  if (id == BRK_27PT_COEFF || id == BRK_MPI125 || id == BRK_MPI7_X2 || id == BRK_7PT_X2) {
+    if (int rc = link_mask(adj, st, &lmask)) return rc; // cube kernels over a registered table: the rows of the list neighbours need not be read
+  } else {
+    if (int rc = face_table(adj, st, &faces)) return rc; // star kernels over a registered table: one 32-byte row of face ids instead of a 108-byte row
+  }
   // default kernels: 7-point family in brk_star7.hip, 13-/25-point in brk_starwg.hip, 27-/125-point and the fused double
   // 7-point sweep in brk_cubedense.hip.  Builds with -DBRK_VARIANTS also carry the earlier generations (brk_set_variant).
 #ifdef BRK_VARIANTS
   if ((id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) && var != 1)
-    return launch_star7(id, var == 0 ? kDefaultStar7Variant : var, adj, in, out, step, ids, first, n, cf, st);
-  if ((id == BRK_MPI13 || id == BRK_MPI25) && var != 1) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st);
+    return launch_star7(id, var == 0 ? kDefaultStar7Variant : var, adj, in, out, step, ids, first, n, cf, st, faces);
+  if ((id == BRK_MPI13 || id == BRK_MPI25) && var != 1) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st, faces);
   if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st, lmask);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = var;
@@ -262,8 +267,8 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   return BRK_OK;
 #else
   (void)var;
-  if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) return launch_star7(id, kDefaultStar7Variant, adj, in, out, step, ids, first, n, cf, st);
-  if (id == BRK_MPI13 || id == BRK_MPI25) return launch_star_wg(id, 0, adj, in, out, step, ids, first, n, cf, st);
+  if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) return launch_star7(id, kDefaultStar7Variant, adj, in, out, step, ids, first, n, cf, st, faces);
+  if (id == BRK_MPI13 || id == BRK_MPI25) return launch_star_wg(id, 0, adj, in, out, step, ids, first, n, cf, st, faces);
   return launch_cube_dense(id, 0, adj, in, out, step, ids, first, n, cf, st, lmask);
 #endif
 }
@@ -457,12 +462,25 @@ __global__ void k_link_mask(const uint32_t *__restrict__ adj, uint32_t nbricks, 
   }
 }
 
+// The six face neighbours of every brick of a registered table as ONE aligned 32-byte row {k-, k+, j-, j+, i-, i+, 0, 0}: what the star
+// kernels need of the 108-byte adjacency row (which straddles two or three 64-byte lines: 60 MB of reads per 512^3 sweep, against 8 MB)
+__global__ void k_face_table(const uint32_t *__restrict__ adj, uint32_t nbricks, uint32_t *__restrict__ faces) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbricks) return;
+  const uint32_t *row = adj + (size_t)b * 27;
+  uint4 lo = {row[adj_slot(-1, 0, 0)], row[adj_slot(1, 0, 0)], row[adj_slot(0, -1, 0)], row[adj_slot(0, 1, 0)]};
+  uint4 hi = {row[adj_slot(0, 0, -1)], row[adj_slot(0, 0, 1)], 0u, 0u};
+  reinterpret_cast<uint4 *>(faces)[2 * (size_t)b] = lo;
+  reinterpret_cast<uint4 *>(faces)[2 * (size_t)b + 1] = hi;
+}
+
 struct AdjEntry {
   const uint32_t *adj;
   uint32_t nbricks;
   int device;
   std::vector<std::pair<std::pair<uint32_t, uint32_t>, uint32_t *>> masks; // (s1, s2) -> device bit mask
   uint32_t *linkmask = nullptr;                                             // k_link_mask, built on first use
+  uint32_t *faces = nullptr;                                                // k_face_table, built on first use
 };
 std::mutex g_adj_mutex;
 std::vector<AdjEntry> g_adj;
@@ -494,6 +512,32 @@ int regular_mask(const uint32_t *adj, uint32_t s1, uint32_t s2, hipStream_t st, 
     }
     e.masks.push_back({{s1, s2}, mask});
     *out = mask;
+    return BRK_OK;
+  }
+  return BRK_OK;
+}
+
+int face_table(const uint32_t *adj, hipStream_t st, const uint32_t **out) {
+  *out = nullptr;
+  std::lock_guard<std::mutex> lock(g_adj_mutex);
+  for (AdjEntry &e : g_adj) {
+    if (e.adj != adj) continue;
+    if (!e.faces) {
+      int device = 0;
+      HIP_TRY(hipGetDevice(&device));
+      if (device != e.device) return brk_fail(BRK_EINVAL, "adjacency table registered on device %d used on device %d", e.device, device);
+      uint32_t *t = nullptr;
+      HIP_TRY(hipMalloc(&t, (size_t)e.nbricks * 8 * sizeof(uint32_t)));
+      hipLaunchKernelGGL(k_face_table, dim3((e.nbricks + 255) / 256), dim3(256), 0, st, adj, e.nbricks, t);
+      hipError_t r = hipGetLastError();
+      if (r == hipSuccess) r = hipStreamSynchronize(st); // the first call for a table is synchronous
+      if (r != hipSuccess) {
+        (void)hipFree(t);
+        HIP_TRY(r);
+      }
+      e.faces = t;
+    }
+    *out = e.faces;
     return BRK_OK;
   }
   return BRK_OK;
@@ -533,7 +577,7 @@ extern "C" int brk_adjacency_register(const uint32_t *adj_dev, uint32_t nbricks)
   std::lock_guard<std::mutex> lock(g_adj_mutex);
   for (const AdjEntry &e : g_adj)
     if (e.adj == adj_dev) return brk_fail(BRK_EINVAL, "brk_adjacency_register: table %p is registered already", (const void *)adj_dev);
-  g_adj.push_back(AdjEntry{adj_dev, nbricks, device, {}, nullptr});
+  g_adj.push_back(AdjEntry{adj_dev, nbricks, device, {}, nullptr, nullptr});
   return BRK_OK;
 }
 
@@ -543,6 +587,7 @@ extern "C" int brk_adjacency_release(const uint32_t *adj_dev) {
     if (g_adj[q].adj == adj_dev) {
       for (auto &m : g_adj[q].masks) (void)hipFree(m.second); // hipFree waits for the kernels that still read it
       if (g_adj[q].linkmask) (void)hipFree(g_adj[q].linkmask);
+      if (g_adj[q].faces) (void)hipFree(g_adj[q].faces);
       g_adj.erase(g_adj.begin() + q);
       return BRK_OK;
     }
@@ -605,9 +650,10 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
   if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) {
-    const uint32_t *regmask = nullptr; // registered adjacency: bricks whose face neighbours are the predicted ones skip their rows
+    const uint32_t *regmask = nullptr, *faces = nullptr; // registered adjacency: bricks whose face neighbours are the predicted ones skip their rows
     if (int rc = regular_mask(adj, tot[0], tot[0] * tot[1], static_cast<hipStream_t>(s), &regmask)) return rc;
-    return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s), regmask);
+    if (int rc = face_table(adj, static_cast<hipStream_t>(s), &faces)) return rc;
+    return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s), regmask, faces);
   }
   // other stencils: the same traversal order as an id list, built once per box geometry and kept on the device
   std::lock_guard<std::mutex> lock(g_box_mutex);

@@ -28,7 +28,12 @@ struct Nbr {
   uint32_t km, kp, jm, jp, im, ip;
 };
 
-__device__ __forceinline__ Nbr load_nbr(const uint32_t *__restrict__ adj, uint32_t b) {
+// faces != nullptr: the compact table of a registered adjacency (k_face_table, brk_kernels.hip): one aligned 32-byte row per brick
+__device__ __forceinline__ Nbr load_nbr(const uint32_t *__restrict__ adj, const uint32_t *__restrict__ faces, uint32_t b) {
+  if (faces) {
+    const uint32_t *f = faces + (size_t)b * 8;
+    return Nbr{f[0], f[1], f[2], f[3], f[4], f[5]};
+  }
   const uint32_t *row = adj + (size_t)b * 27;
   Nbr n;
   n.km = row[adj_slot(-1, 0, 0)];
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(kWG, 6) void k_s7(const uint32_t *__restrict__ adj,
   const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
   if (b == BRK_LIST_SKIP) return;
   Faces f;
-  issue_loads(f, in, step, b, load_nbr(adj, b), lane);
+  issue_loads(f, in, step, b, load_nbr(adj, nullptr, b), lane);
   stage(tile, f, lane);
   wave_lds_sync();
   compute_store<MPI>(tile, f, out + (size_t)b * step, lane, cf);
@@ -232,7 +237,8 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
                                                                       double *__restrict__ out, size_t step,
                                                                       const uint32_t *__restrict__ ids, uint32_t first,
                                                                       uint32_t n, Box bx, Coeffs cf,
-                                                                      const uint32_t *__restrict__ regmask) {
+                                                                      const uint32_t *__restrict__ regmask,
+                                                                      const uint32_t *__restrict__ faces) {
   __shared__ double lds[NW * kTile];
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -287,14 +293,14 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
     if (use_mask) mword = (DIAG & 16) ? 0xFFFFFFFFu : regmask[b >> 5]; // DIAG 16: the mask path without its load (timing experiment)
     Nbr nb{};
     if (DIAG & 1) nb = Nbr{b - bx.ni_tot * bx.nj_tot, b + bx.ni_tot * bx.nj_tot, b - bx.ni_tot, b + bx.ni_tot, b - 1, b + 1};
-    else if (!use_mask) nb = load_nbr(adj, b);
+    else if (!use_mask) nb = load_nbr(adj, faces, b);
     const gcptr self = sbase(in + (size_t)b * step);
 #pragma unroll
     for (int k = 0; k < 8; ++k) f.own[k] = BRK_LD_OWN(&self[k * 64 + lane]);
     __builtin_amdgcn_sched_barrier(0); // own loads are in flight before anything waits for the mask word / the adjacency row
     if (use_mask) {
       if ((mword >> (b & 31u)) & 1u) nb = Nbr{b - bx.ni_tot * bx.nj_tot, b + bx.ni_tot * bx.nj_tot, b - bx.ni_tot, b + bx.ni_tot, b - 1, b + 1};
-      else nb = load_nbr(adj, b);
+      else nb = load_nbr(adj, faces, b);
     }
     if ((DIAG & 4) || ((DIAG & 2) && (diag_edge & 1u))) nb.jm = b;
     if ((DIAG & 4) || ((DIAG & 2) && (diag_edge & 2u))) nb.jp = b;
@@ -365,12 +371,12 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
 } // namespace
 
 int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step,
-                 const uint32_t *ids, uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
+                 const uint32_t *ids, uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *faces) {
   const int kind = stencil_id == BRK_MPI7 ? kMpi : (stencil_id == BRK_COND7 ? kCond : kCoeff);
   // workgroups of 8 waves sharing i-faces (variant 5, the default); -DBRK_VARIANTS builds: 6 = 4-wave groups, 2 = one brick per
   // wave with every face gathered
 #define BRK_LAUNCH_WG(M, W, I) \
-  hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf, nullptr)
+  hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf, nullptr, faces)
 #define BRK_LAUNCH_WG_K(K, W)                      \
   do {                                            \
     if (ids) BRK_LAUNCH_WG(K, W, kModeList);      \
@@ -411,7 +417,7 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
 // Box mode (brk_stencil_apply_box): no id list; see struct Box.
 int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, double *out, size_t step, uint32_t base,
                      const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const Coeffs &cf, hipStream_t st,
-                     const uint32_t *regmask) {
+                     const uint32_t *regmask, const uint32_t *faces) {
   Box bx{base, tot[0], tot[1], {lo[0], lo[1], lo[2]}, {cnt[0], cnt[1], cnt[2]}};
   const uint32_t G = (cnt[0] + 7) / 8;
   uint32_t per_xcd = 0;
@@ -424,7 +430,7 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
 #ifdef BRK_DIAG
   if (g_diag) {
 #define BRK_DIAG_CASE(D) \
-  if (g_diag == D) hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox, D>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask)
+  if (g_diag == D) hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox, D>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask, faces)
     BRK_DIAG_CASE(16); BRK_DIAG_CASE(1); BRK_DIAG_CASE(2); BRK_DIAG_CASE(3); BRK_DIAG_CASE(4); BRK_DIAG_CASE(5); BRK_DIAG_CASE(8); BRK_DIAG_CASE(12); BRK_DIAG_CASE(13);
 #undef BRK_DIAG_CASE
     HIP_TRY(hipGetLastError());
@@ -432,11 +438,11 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
   }
 #endif
   if (stencil_id == BRK_MPI7)
-    hipLaunchKernelGGL((k_s7_wg<kMpi, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask);
+    hipLaunchKernelGGL((k_s7_wg<kMpi, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask, faces);
   else if (stencil_id == BRK_COND7)
-    hipLaunchKernelGGL((k_s7_wg<kCond, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask);
+    hipLaunchKernelGGL((k_s7_wg<kCond, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask, faces);
   else
-    hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask);
+    hipLaunchKernelGGL((k_s7_wg<kCoeff, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask, faces);
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

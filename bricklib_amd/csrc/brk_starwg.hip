@@ -51,7 +51,7 @@ namespace {
 template <int KIND, int NW, int OCC, int DIAG = 0>
 __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
-    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
+    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf, const uint32_t *__restrict__ faces) {
   constexpr int R = StarTraits<KIND>::R;
   using TL = WgTile<R>;
   __shared__ double lds[NW * TL::TILE];
@@ -80,13 +80,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
 #pragma unroll
     for (int k = 0; k < 8; ++k) col[R + k] = self[k * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);
-    const uint32_t *row = adj + (size_t)b * 27;
-    const uint32_t n_km = __builtin_amdgcn_readfirstlane(row[adj_slot(-1, 0, 0)]);
-    const uint32_t n_kp = __builtin_amdgcn_readfirstlane(row[adj_slot(1, 0, 0)]);
-    const uint32_t n_jm = __builtin_amdgcn_readfirstlane(row[adj_slot(0, -1, 0)]);
-    const uint32_t n_jp = __builtin_amdgcn_readfirstlane(row[adj_slot(0, 1, 0)]);
-    const uint32_t n_im = __builtin_amdgcn_readfirstlane(row[adj_slot(0, 0, -1)]);
-    const uint32_t n_ip = __builtin_amdgcn_readfirstlane(row[adj_slot(0, 0, 1)]);
+    // registered adjacency: the six face ids come from one aligned 32-byte row of the compact table (k_face_table, brk_kernels.hip)
+    const uint32_t *row = faces ? faces + (size_t)b * 8 : adj + (size_t)b * 27;
+    const uint32_t n_km = __builtin_amdgcn_readfirstlane(row[faces ? 0 : adj_slot(-1, 0, 0)]);
+    const uint32_t n_kp = __builtin_amdgcn_readfirstlane(row[faces ? 1 : adj_slot(1, 0, 0)]);
+    const uint32_t n_jm = __builtin_amdgcn_readfirstlane(row[faces ? 2 : adj_slot(0, -1, 0)]);
+    const uint32_t n_jp = __builtin_amdgcn_readfirstlane(row[faces ? 3 : adj_slot(0, 1, 0)]);
+    const uint32_t n_im = __builtin_amdgcn_readfirstlane(row[faces ? 4 : adj_slot(0, 0, -1)]);
+    const uint32_t n_ip = __builtin_amdgcn_readfirstlane(row[faces ? 5 : adj_slot(0, 0, 1)]);
     const uint32_t b_prev = w > 0 ? __builtin_amdgcn_readfirstlane(id_of(slot - 1)) : 0xFFFFFFFFu;
     const uint32_t b_next = (w + 1 < NW && slot + 1 < n) ? __builtin_amdgcn_readfirstlane(id_of(slot + 1)) : 0xFFFFFFFFu;
     share_im = n_im == b_prev;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
 } // namespace
 
 int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                   uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st) {
+                   uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *faces) {
   // Smaller workgroups = more of them resident and less lockstep between the load and the compute phase; larger ones share more
   // i-faces.  Measured at 512^3: 13-pt 4 waves (32 KiB LDS, 5 groups = 20 waves/CU) 0.392 ms vs 8 waves (64 KiB, 16 waves/CU)
   // 0.408 ms; 25-pt (12 KiB of LDS per wave, 12 waves/CU either way) 4 waves 0.502 ms vs 2 waves 0.507 ms -- since every line of a
@@ -220,13 +221,13 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
 #ifdef BRK_VARIANTS
   if (stencil_id == BRK_MPI13 && variant == 2) {
     const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 8, 4>), dim3(wgs), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 8, 4>), dim3(wgs), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
     HIP_TRY(hipGetLastError());
     return BRK_OK;
   }
   if (stencil_id == BRK_MPI25 && variant == 2) {
     const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
-    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
     HIP_TRY(hipGetLastError());
     return BRK_OK;
   }
@@ -235,7 +236,7 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
   if (stencil_id == BRK_MPI25 && variant >= 7 && variant <= 12) {
     // timing experiments: 7 = no k-face loads, 8 = no j-face loads, 9 = neither; 10 = k-faces read from the brick itself, 11 = j-faces, 12 = both
     const uint32_t wgs = (((n + 1) / 2 + 7) / 8) * 8;
-#define BRK_DIAG25(V, D) if (variant == V) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, D>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf)
+#define BRK_DIAG25(V, D) if (variant == V) hipLaunchKernelGGL((k_star_wg<kStarMpi25, 2, 3, D>), dim3(wgs), dim3(128), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces)
     BRK_DIAG25(7, 1); BRK_DIAG25(8, 2); BRK_DIAG25(9, 3); BRK_DIAG25(10, 4); BRK_DIAG25(11, 8); BRK_DIAG25(12, 12);
 #undef BRK_DIAG25
     HIP_TRY(hipGetLastError());
@@ -245,9 +246,9 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
   (void)variant;
   const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
   if (stencil_id == BRK_MPI13)
-    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 4, 5>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi13, 4, 5>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
   else
-    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 4, 3>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    hipLaunchKernelGGL((k_star_wg<kStarMpi25, 4, 3>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

@@ -1197,12 +1197,12 @@ def test_registered_adjacency_box_form_is_bit_identical(oracle, dev):
     ids_all = np.ascontiguousarray(grid.reshape(shape[2], shape[1], shape[0])[1:-1, 1:-1, 1:-1]).reshape(-1)
     from bricklib_amd.order import tiled
     lists = [tiled(grid.reshape(shape[2], shape[1], shape[0])[1:-1, 1:-1, 1:-1]), ids_all, ids_all[3:-5:2].copy(), rng.permutation(ids_all).astype(np.uint32)]
-    for name in ("27pt", "mpi125pt", "mpi7pt_x2"):
+    for name in ("27pt", "mpi125pt", "mpi7pt_x2", "7pt", "mpi7pt", "mpi13pt", "mpi25pt"):   # star kernels: compact face table
         for ids in lists:
             outs = []
             for info in (bl.BrickInfo(raw), bl.BrickInfo(adj, dev)):
                 stB = bl.BrickStorage.allocate(nbricks, 512, dev)
-                bl.apply_stencil(name, bl.Brick(info, stA, 0), bl.Brick(info, stB, 0), ids=grid_to_device(ids, dev), coeff=oracle.coeffs(129, 1) if name == "27pt" else None)
+                bl.apply_stencil(name, bl.Brick(info, stA, 0), bl.Brick(info, stB, 0), ids=grid_to_device(ids, dev), coeff=oracle.coeffs(129, 1) if name in ("27pt", "7pt") else None)
                 outs.append(stB.dat.clone())
             assert torch.equal(outs[0], outs[1]), (name, ids.size)
             assert outs[0].abs().max().item() > 0
