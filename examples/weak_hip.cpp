@@ -35,6 +35,7 @@ int main(int argc, char **argv) {
   populate_cart(bDecomp, cart, coo);
   BrickInfo<3> bInfo = bDecomp.getBrickInfo();
   BrickInfo<3> bInfo_dev = movBrickInfo(bInfo, hipMemcpyHostToDevice);
+  brkRegisterAdjacency(bInfo_dev); // written once: the library may keep compact tables next to it (brk_adjacency_register)
   const size_t bsize = 512;
   auto bStorage = bInfo.allocate(bsize), bOther = bInfo.allocate(bsize);
   const size_t total = (size_t)bStorage.chunks * bStorage.step;

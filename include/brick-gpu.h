@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "brick.h"
+#include "brk.h"
 
 #define gpuCheck(x) _gpuCheck(x, #x, __FILE__, __LINE__)
 
@@ -44,6 +45,24 @@ BrickInfo<dims> *movBrickInfoDeep(BrickInfo<dims> &bInfo, gpuMemcpyKind kind) {
     ret = (BrickInfo<dims> *)malloc(sizeof(BrickInfo<dims>));
   gpuCheck(gpuMemcpy(ret, &temp, sizeof(BrickInfo<dims>), kind));
   return ret;
+}
+
+// OPTIONAL (not in the reference): promise that the DEVICE adjacency list of `bInfo_dev` is not written again until
+// brkReleaseAdjacency(bInfo_dev) -- what every driver of the reference does anyway (BrickInfo is filled once by init_grid /
+// BrickDecomp::getBrickInfo).  libbrk.so may then keep derived tables next to it (brk_adjacency_register in brk.h: predicted
+// face neighbours, compact face rows, link bits) and read fewer adjacency bytes per sweep; results are identical.  Release BEFORE
+// gpuFree(bInfo_dev.adj).  Needs libbrk.so (brk.h); a table that is never registered works as before.
+template <unsigned dims>
+inline void brkRegisterAdjacency(const BrickInfo<dims> &bInfo_dev) {
+  static_assert(dims == 3, "the stencil engine is three-dimensional");
+  if (brk_adjacency_register(reinterpret_cast<const uint32_t *>(bInfo_dev.adj), bInfo_dev.nbricks) != BRK_OK) {
+    printf("brkRegisterAdjacency: %s\n", brk_last_error());
+    exit(EXIT_FAILURE);
+  }
+}
+template <unsigned dims>
+inline void brkReleaseAdjacency(const BrickInfo<dims> &bInfo_dev) {
+  (void)brk_adjacency_release(reinterpret_cast<const uint32_t *>(bInfo_dev.adj));
 }
 
 // new BrickStorage on the destination side holding a copy of the data
