@@ -39,6 +39,7 @@ def _load():
         f.restype = C.c_int
     L.brk_stencil_apply_range.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32, f64p, vp]
     L.brk_stencil_apply_list.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, vp, C.c_uint32, f64p, vp]
+    L.brk_stencil_apply_list_kpaired.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, vp, C.c_uint32, f64p, vp]
     U3 = C.c_uint32 * 3
     L.brk_stencil_apply_box.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, U3, U3, U3, f64p, vp]
     L.brk_stencil_apply_taps.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -132,7 +133,7 @@ lib = _load()
 # every symbol include/brk.h declares (tests check the library exports each of them)
 ABI_SYMBOLS = [
     "brk_last_error", "brk_abi_version", "brk_stencil_radius", "brk_stencil_ncoeff", "brk_stencil_iters",
-    "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_stencil_apply_box", "brk_stencil_apply_taps", "brk_set_variant", "brk_link_copy", "brk_array_to_brick",
+    "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_stencil_apply_list_kpaired", "brk_stencil_apply_box", "brk_stencil_apply_taps", "brk_set_variant", "brk_link_copy", "brk_array_to_brick",
     "brk_brick_to_array", "brk_compare_brick", "brk_init_grid", "brk_decomp_build", "brk_decomp_free",
     "brk_decomp_nbricks", "brk_decomp_grid_size", "brk_decomp_tdims", "brk_decomp_sep_pos", "brk_decomp_grid",
     "brk_decomp_adj", "brk_decomp_nruns", "brk_decomp_ghost", "brk_decomp_skin", "brk_decomp_nskin",

@@ -47,7 +47,7 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
 
 // 13-/25-point kernels with workgroup-shared i-halos (brk_starwg.hip)
 int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                   uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *faces);
+                   uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *faces, bool kpaired);
 
 // 27-/125-point kernels: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip), and the earlier padded
 // tiles with shared i-halos (brk_cubewg.hip)

@@ -216,7 +216,7 @@ int link_mask(const uint32_t *adj, hipStream_t st, const uint32_t **out);
 int face_table(const uint32_t *adj, hipStream_t st, const uint32_t **out);
 
 int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                   uint32_t first, uint32_t n, const double *coeff_host, brk_stream s) {
+                   uint32_t first, uint32_t n, const double *coeff_host, brk_stream s, bool kpaired = false) {
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
   if (!adj || !in || !out) return brk_fail(BRK_EINVAL, "null device pointer");
   if (in == out) return brk_fail(BRK_EINVAL, "in and out must be different fields");
@@ -239,7 +239,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
 #ifdef BRK_VARIANTS
   if ((id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) && var != 1)
     return launch_star7(id, var == 0 ? kDefaultStar7Variant : var, adj, in, out, step, ids, first, n, cf, st, faces);
-  if ((id == BRK_MPI13 || id == BRK_MPI25) && var != 1) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st, faces);
+  if ((id == BRK_MPI13 || id == BRK_MPI25) && var != 1) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st, faces, kpaired);
   if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st, lmask);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = var;
@@ -266,9 +266,8 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 #else
-  (void)var;
   if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) return launch_star7(id, kDefaultStar7Variant, adj, in, out, step, ids, first, n, cf, st, faces);
-  if (id == BRK_MPI13 || id == BRK_MPI25) return launch_star_wg(id, 0, adj, in, out, step, ids, first, n, cf, st, faces);
+  if (id == BRK_MPI13 || id == BRK_MPI25) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st, faces, kpaired);
   return launch_cube_dense(id, 0, adj, in, out, step, ids, first, n, cf, st, lmask);
 #endif
 }
@@ -307,7 +306,7 @@ extern "C" void brk_debug_diag(int d) { brk::g_diag = d; }
 extern "C" int brk_set_variant(int id, int v) {
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
 #ifndef BRK_VARIANTS
-  if (v != 0) return brk_fail(BRK_EINVAL, "kernel variant %d: this build carries the default kernels only (make -C bricklib_amd/csrc VARIANTS=1 adds the earlier generations)", v);
+  if (v != 0 && !((id == BRK_MPI13 || id == BRK_MPI25) && v == 3)) return brk_fail(BRK_EINVAL, "kernel variant %d: this build carries the default kernels only (make -C bricklib_amd/csrc VARIANTS=1 adds the earlier generations)", v);
 #endif
   g_variant[id] = v;
   return BRK_OK;
@@ -355,11 +354,14 @@ void reap_retired_locked() {
 }
 
 // caller holds g_box_mutex
-// rows_per_block: j-rows of an XCD slab swept over all k before the next block (the distance between the two uses of a k-face)
-int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], uint32_t rows_per_block, BoxList **entry) {
+// rows_per_block: j-rows of an XCD slab swept over all k before the next block (the distance between the two uses of a k-face).
+// kpair: the k-paired order of k_star_kp -- inside a block two k-levels at a time, every run of 4 i-neighbours at k followed by the
+// same run at k+1 (rows padded to multiples of 4 entries; an odd last level is paired with skipped entries)
+int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], uint32_t rows_per_block, bool kpair,
+                    BoxList **entry) {
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
-  const uint32_t key[12] = {(uint32_t)device, base, tot[0], tot[1], tot[2], lo[0], lo[1], lo[2], cnt[0], cnt[1], cnt[2], rows_per_block};
+  const uint32_t key[12] = {(uint32_t)device, base, tot[0], tot[1], tot[2], lo[0], lo[1], lo[2], cnt[0], cnt[1], cnt[2], rows_per_block | (kpair ? 0x100u : 0u)};
   int victim = 0;
   for (int q = 0; q < kBoxCache; ++q) {
     if (g_box[q].dev && std::memcmp(g_box[q].key, key, sizeof key) == 0) {
@@ -377,13 +379,27 @@ int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], 
     for (uint32_t i = 0; i < ni; ++i) v.push_back(id_at(k, j, i));
     if (rowlen != ni) v.push_back(BRK_LIST_SKIP);
   };
+  // two k-levels of one row interleaved in runs of 4: [i..i+3 at k][i..i+3 at k+1]; k1 == nk: the upper level does not exist
+  auto push_row_pair = [&](std::vector<uint32_t> &v, uint32_t k0, uint32_t k1, uint32_t j) {
+    for (uint32_t i0 = 0; i0 < ni; i0 += 4)
+      for (uint32_t k : {k0, k1})
+        for (uint32_t i = i0; i < i0 + 4; ++i) v.push_back(i < ni && k < nk ? id_at(k, j, i) : BRK_LIST_SKIP);
+  };
   for (uint32_t x = 0; x < 8; ++x) {
     for (uint32_t j0 = x * jbase; j0 < (x + 1) * jbase; j0 += rows_per_block)
-      for (uint32_t k = 0; k < nk; ++k)
-        for (uint32_t j = j0; j < j0 + rows_per_block && j < (x + 1) * jbase; ++j) push_row(part[x], k, j);
-    if (rem)
-      for (uint32_t k = (uint32_t)((uint64_t)nk * x / 8); k < (uint32_t)((uint64_t)nk * (x + 1) / 8); ++k)
-        for (uint32_t j = nj - rem; j < nj; ++j) push_row(part[x], k, j);
+      for (uint32_t k = 0; k < nk; k += kpair ? 2 : 1)
+        for (uint32_t j = j0; j < j0 + rows_per_block && j < (x + 1) * jbase; ++j) {
+          if (kpair) push_row_pair(part[x], k, k + 1, j);
+          else push_row(part[x], k, j);
+        }
+    if (rem) {
+      const uint32_t ka = (uint32_t)((uint64_t)nk * x / 8), kb = (uint32_t)((uint64_t)nk * (x + 1) / 8);
+      for (uint32_t k = ka; k < kb; k += kpair ? 2 : 1)
+        for (uint32_t j = nj - rem; j < nj; ++j) {
+          if (kpair) push_row_pair(part[x], k, k + 1 < kb ? k + 1 : nk, j);
+          else push_row(part[x], k, j);
+        }
+    }
   }
   size_t per = 0;
   for (auto &v : part) per = v.size() > per ? v.size() : per;
@@ -606,6 +622,12 @@ extern "C" int brk_stencil_apply_list(int id, const uint32_t *adj, const double 
   return launch_stencil(id, adj, in, out, step, ids, 0, n, coeff_host, s);
 }
 
+extern "C" int brk_stencil_apply_list_kpaired(int id, const uint32_t *adj, const double *in, double *out, size_t step,
+                                              const uint32_t *ids, uint32_t n, const double *coeff_host, brk_stream s) {
+  if (n && !ids) return brk_fail(BRK_EINVAL, "null brick id list");
+  return launch_stencil(id, adj, in, out, step, ids, 0, n, coeff_host, s, true);
+}
+
 extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                                       uint32_t first, uint32_t n, uint32_t ntaps, const int32_t *offsets_host,
                                       const double *weights_host, brk_stream s) {
@@ -662,8 +684,9 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
   // the k-halo lines in the 4-MiB L2 until the brick itself is swept (fabric reads 1.05 -> 0.73 GB, FETCH_SIZE 709 174 KB, traffic
   // 3.18 -> 2.53 GB per 512^3 sweep) but the sweep takes 0.500-0.508 ms instead of 0.493-0.495: the extra reads are served by the
   // Infinity Cache and are not what bounds the kernel, the shorter rows-in-flight window is (profiles/r03_d_25pt_rows_per_block.txt).
-  if (int rc = box_list_locked(base, tot, lo, cnt, 8u, &e)) return rc;
-  if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s)) return rc;
+  const bool kpair = id == BRK_MPI25; // the radius-4 star runs two bricks per wave over k-paired lists (k_star_kp, brk_starwg.hip)
+  if (int rc = box_list_locked(base, tot, lo, cnt, 8u, kpair, &e)) return rc;
+  if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s, kpair)) return rc;
   HIP_TRY(hipEventRecord(e->last_use, static_cast<hipStream_t>(s)));
   return BRK_OK;
 }

@@ -18,7 +18,20 @@ def _pad(a, n):
     return a if a.size == n else np.concatenate([a, np.full(n - a.size, LIST_SKIP, dtype=np.uint32)])
 
 
-def slabs(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True):
+def _pair_levels(ids3):
+    """[nk][nj][ni] -> [ceil(nk/2)][nj][8 * ceil(ni/4)]: two k-levels of a row interleaved in runs of 4 i-neighbours,
+    [i..i+3 at k][i..i+3 at k+1], LIST_SKIP where a run is shorter or the upper level does not exist: the k-paired order of
+    k_star_kp (brk_starwg.hip), in which a wave computes entry w of the first run and entry w of the second"""
+    nk, nj, ni = ids3.shape
+    ni4 = (ni + 3) // 4 * 4
+    nk2 = (nk + 1) // 2 * 2
+    pad = np.full((nk2, nj, ni4), LIST_SKIP, dtype=np.uint32)
+    pad[:nk, :, :ni] = ids3
+    p = pad.reshape(nk2 // 2, 2, nj, ni4 // 4, 4)          # [pair][level][j][run][entry]
+    return np.ascontiguousarray(p.transpose(0, 2, 3, 1, 4)).reshape(nk2 // 2, nj, 2 * ni4)
+
+
+def slabs(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True, kpair=False):
     """Per-XCD pieces of the tiled order of `ids3` ([nk][nj][ni] brick ids): XCD x gets its own slab of nj // nxcd
     j-rows, swept in blocks of <= rows_per_block rows over all k, i fastest; the nj % nxcd left-over rows are cut along k
     instead, one k-range per XCD, so that every XCD gets the same amount of work (66 rows: 8 each + 2 rows x 1/8 of the
@@ -26,6 +39,9 @@ def slabs(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True):
     behind it, so that two rows never meet inside a workgroup without an idle wave between them (the kernels park
     fallback halos in an idle wave's LDS slot; two active non-neighbours side by side cost a second phase)."""
     ids3 = np.asarray(ids3).astype(np.uint32)
+    if kpair:   # every entry of the "k" axis now stands for a pair of levels; rows are multiples of 8 entries (no padding entry needed)
+        ids3 = _pair_levels(ids3)
+        pad_rows = False
     nk, nj, ni = ids3.shape
     if pad_rows and ni % 8:
         ids3 = np.concatenate([ids3, np.full((nk, nj, 1), LIST_SKIP, dtype=np.uint32)], axis=2)
@@ -58,9 +74,10 @@ def chunks(ids, nxcd=NXCD):
     return [ids[x * per:(x + 1) * per] for x in range(nxcd)]
 
 
-def tiled(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True):
-    """Flat tiled list of `ids3` ([nk][nj][ni] brick ids), see slabs()/assemble()."""
-    return assemble(slabs(ids3, rows_per_block, nxcd, pad_rows), nxcd=nxcd)
+def tiled(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True, kpair=False):
+    """Flat tiled list of `ids3` ([nk][nj][ni] brick ids), see slabs()/assemble().  kpair: the k-paired order for
+    apply_stencil(..., kpaired=True) -- same bricks, runs of 4 i-neighbours at k followed by the same run at k+1."""
+    return assemble(slabs(ids3, rows_per_block, nxcd, pad_rows, kpair), nxcd=nxcd)
 
 
 def _box(grid, lo, hi):

@@ -26,10 +26,11 @@ def stencil_iters(stencil):
     return lib.brk_stencil_iters(_sid(stencil))
 
 
-def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coeff=None, stream=None):
+def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coeff=None, stream=None, kpaired=False):
     """out[b] = stencil(in[b], neighbours) for b in `ids` (device int32 tensor holding uint32 brick ids, e.g.
     the reference's `grid`), in brick_range=(begin,end), or in box=(base, tot[3], lo[3], cnt[3]) of a lexicographic
-    numbering (contiguous axis first).  bIn/bOut: Brick objects sharing one BrickInfo."""
+    numbering (contiguous axis first).  bIn/bOut: Brick objects sharing one BrickInfo.  kpaired: `ids` is in the k-paired
+    order of bricklib_amd.order.tiled(..., kpair=True) (brk_stencil_apply_list_kpaired: faster for the 25-point star, same results)."""
     sid = _sid(stencil)
     cp = None
     if coeff is not None:
@@ -43,7 +44,7 @@ def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coef
                                         U3(*[int(x) for x in tot]), U3(*[int(x) for x in lo]), U3(*[int(x) for x in cnt]),
                                         cp, _stream(stream)))
     elif ids is not None:
-        check(lib.brk_stencil_apply_list(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids),
+        check((lib.brk_stencil_apply_list_kpaired if kpaired else lib.brk_stencil_apply_list)(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids),
                                          ids.numel(), cp, _stream(stream)))
     else:
         b0, b1 = brick_range if brick_range is not None else (0, bIn.bInfo.nbricks)

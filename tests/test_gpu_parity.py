@@ -1212,3 +1212,40 @@ def test_registered_adjacency_box_form_is_bit_identical(oracle, dev):
     assert lib.brk_adjacency_register(C.c_void_p(t.data_ptr()), nbricks) != 0
     check(lib.brk_adjacency_release(C.c_void_p(t.data_ptr())))
     assert lib.brk_adjacency_release(C.c_void_p(t.data_ptr())) != 0
+
+
+@pytest.mark.parametrize("shape", [(10, 10, 10), (7, 21, 5), (14, 6, 9), (66, 11, 4)])
+def test_star_two_bricks_per_wave_kpaired_lists(oracle, dev, shape):
+    """k_star_kp (two bricks per wave; the planes between the two bricks of a k-pair are loaded once): the 25-point star over
+    k-paired lists (brk_stencil_apply_list_kpaired; order.tiled(kpair=True)) with odd level counts, rows that are not multiples
+    of 4 and fewer rows than XCDs, and -- forced by variant 3, also for the 13-point star -- over lists that are NOT paired:
+    tiled, lexicographic, ragged, shuffled.  Always the oracle's result."""
+    from bricklib_amd._lib import lib
+    from bricklib_amd.order import tiled
+    ni, nj, nk = shape
+    grid, info = bl.init_grid(shape, dev)
+    g3 = grid.reshape(nk, nj, ni)[1:-1, 1:-1, 1:-1]
+    rng = np.random.default_rng(12)
+    st = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    st.dat.copy_(torch.from_numpy(rng.random(info.nbricks * 512)))
+    hin = st.dat.cpu().numpy()
+    flat = np.ascontiguousarray(g3).reshape(-1)
+    lists = {"kpaired": tiled(g3, kpair=True), "kpaired4": tiled(g3, rows_per_block=4, kpair=True), "tiled": tiled(g3), "lexi": flat,
+             "ragged": flat[1:-3:3].copy(), "shuffled": rng.permutation(flat).astype(np.uint32)}
+    for name, sid in (("mpi25pt", ST_MPI25), ("mpi13pt", ST_MPI13)):
+        want = {}
+        for lname, ids in lists.items():
+            real = ids[ids != 0xFFFFFFFF]
+            w = np.zeros_like(hin)
+            oracle.brick_stencil(sid, info.adj_host, hin, w, 512, ids=np.ascontiguousarray(real))
+            want[lname] = w
+        try:
+            for variant in (0, 3):
+                assert lib.brk_set_variant(sid, variant) == 0
+                for lname, ids in lists.items():
+                    out = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+                    bl.apply_stencil(name, bl.Brick(info, st, 0), bl.Brick(info, out, 0), ids=grid_to_device(ids, dev), kpaired=lname.startswith("kpaired"))
+                    err = np.abs(out.dat.cpu().numpy() - want[lname]).max()
+                    assert err <= TOL, (name, variant, lname, err)
+        finally:
+            lib.brk_set_variant(sid, 0)

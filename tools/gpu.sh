@@ -149,6 +149,11 @@ prio)    # diagnostic build: compute phase (bit 64) / fetch phase (bit 128) of t
   for sid in 5 1 7; do run -n 512 -s $sid -S -o 8 -v 0,7400,13800 -i 40 -r2 4; done ;;
 reg7d)   # diagnostic build: registered-adjacency mask path against its bounds (D 16 = mask path without the mask load, D 1 = no adjacency at all)
   run -n 512 -s 0 -S -b -v 0,100,300,200 -i 100 -r2 6 ;;
+kpair)   # star kernels: two bricks per wave over k-paired lists (variant 3) against the default kernel on its tiled list
+  for sid in 4 3; do
+    run -n 512 -s $sid -S -o 8 -v 0 -i 40 -r2 3
+    for o in 8 4 2; do run -n 512 -s $sid -S -o $o -P -v 3,0 -i 40 -r2 3; done
+  done ;;
 regstar) # star kernels (list form) with / without brk_adjacency_register: compact face table instead of the 108-byte rows
   for sid in 0 3 4; do run -n 512 -s $sid -S -o 8 -v 0,100 -i 40 -r2 4; done ;;
 regcube) # cube kernels (list form) with / without brk_adjacency_register: rows of the list neighbours replaced by link bits

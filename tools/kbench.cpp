@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_stream2_persist(const double *in, doubl
 
 int main(int argc, char **argv) {
   int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1, rounds = 2;
-  bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false, reg = false;
+  bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false, reg = false, kpair = false;
   std::vector<int> variants = {1, 2, 5};
   for (int a = 1; a < argc; ++a) {
     std::string o = argv[a];
@@ -173,6 +173,7 @@ int main(int argc, char **argv) {
     else if (o == "-S") separate = true;   // lexicographic list but two storages (step 512)
     else if (o == "-o") order = atoi(argv[++a]); // 0 lexi; J>0: per-XCD j-slabs of 8 rows, swept in sub-blocks of J rows over all k
     else if (o == "-k") kstack = atoi(argv[++a]); // with -o: workgroup = 8 i-bricks x kstack k-levels
+    else if (o == "-P") kpair = true;      // with -o: k-paired order -- runs of 4 i-neighbours at k followed by the same run at k+1 (k_star_kp)
     else if (o == "-R") reg = true;        // brk_adjacency_register: the table is promised immutable
     else if (o == "-c") stream = true;     // also run the streaming-ceiling kernels
     else if (o == "-D") {                  // diagnostic builds of libbrk.so: timing experiment of the 7-point box kernel
@@ -223,6 +224,15 @@ int main(int argc, char **argv) {
       // XCD x gets rows [x*NB/8, (x+1)*NB/8); inside: blocks of `order` rows swept over all k (k-reuse distance =
       // order*NB bricks), i fastest
       const long rows = NB / 8;
+      if (kpair) {
+        for (long x = 0; x < 8; ++x)
+          for (long jb = 0; jb < rows; jb += order)
+            for (long k = 1; k < SB - 1; k += 2)
+              for (long j = x * rows + jb; j < x * rows + jb + order && j < (x + 1) * rows; ++j)
+                for (long ib = 1; ib < SB - 1; ib += 4)
+                  for (long s2 = 0; s2 < 2; ++s2)
+                    for (long i = ib; i < ib + 4; ++i) ids.push_back(k + s2 < SB - 1 ? grid[((k + s2) * SB + (j + 1)) * SB + i] : BRK_LIST_SKIP);
+      } else
       for (long x = 0; x < 8; ++x)
         for (long jb = 0; jb < rows; jb += order)
           for (long k = 1; k < SB - 1; k += kstack)
