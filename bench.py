@@ -544,15 +544,16 @@ def run_weak(args, bl, dev, rank, world):
         schedule, deep_depth = min(cost, key=cost.get)
     overlap = schedule != "plain"
     state = {}
+    kp = name == "mpi25pt"     # the radius-4 star sweeps k-paired lists (two bricks per wave, brk_stencil_apply_list_kpaired)
     if schedule == "deep":
-        lists = TrapezoidLists(d, S, dev)
-        whole = SweepLists(d, dev)
+        lists = TrapezoidLists(d, S, dev, kpair=kp)
+        whole = SweepLists(d, dev, kpair=kp)
         deep_depth = S if not deep_depth else max(1, min(deep_depth, S))
 
         def step():
             return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=xstream, depth=deep_depth, full=whole)
     else:
-        lists = SweepLists(d, dev)
+        lists = SweepLists(d, dev, kpair=kp)
 
         def step():
             return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=xstream, overlap=overlap, lists=lists, state=state)

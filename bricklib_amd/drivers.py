@@ -16,10 +16,12 @@ from .stencils import apply_stencil, stencil_iters
 
 class SweepLists:
     """Device-resident brick lists of one BrickDecomp for the sweep schedule (same brick sets as the id ranges in
-    the module docstring, but in the cache-friendly order of bricklib_amd.order)."""
+    the module docstring, but in the cache-friendly order of bricklib_amd.order).  kpair: the k-paired order (two bricks per
+    wave for the 25-point star, brk_stencil_apply_list_kpaired); the sweeps below read it from `kpaired`."""
 
-    def __init__(self, d, device, rows_per_block=8):
-        for name, ids in decomp_lists(d, rows_per_block).items():
+    def __init__(self, d, device, rows_per_block=8, kpair=False):
+        self.kpaired = bool(kpair)
+        for name, ids in decomp_lists(d, rows_per_block, kpair=kpair).items():
             setattr(self, name, grid_to_device(ids, device))
 
 
@@ -36,7 +38,7 @@ def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, ove
 
     def sweep(src, dst, which):
         if lists is not None:
-            apply_stencil(stencil, src, dst, ids=getattr(lists, which), coeff=coeff, stream=main)
+            apply_stencil(stencil, src, dst, ids=getattr(lists, which), coeff=coeff, stream=main, kpaired=lists.kpaired)
         else:
             rng = {"inner": (1, sep0), "shell": (sep0, sep2), "surface": (sep0, sep1), "all": (1, sep2),
                    "domain": (1, sep1)}[which]
@@ -74,8 +76,9 @@ def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, ove
 class TrapezoidLists:
     """Device-resident lists of bricklib_amd.order.trapezoid_lists for `sweeps` sweeps per exchange."""
 
-    def __init__(self, d, sweeps, device, rows_per_block=8):
-        inner, shell = trapezoid_lists(d, sweeps, rows_per_block)
+    def __init__(self, d, sweeps, device, rows_per_block=8, kpair=False):
+        self.kpaired = bool(kpair)
+        inner, shell = trapezoid_lists(d, sweeps, rows_per_block, kpair=kpair)
         self.inner = [grid_to_device(x, device) if x.size else None for x in inner]
         self.shell = [grid_to_device(x, device) if x.size else None for x in shell]
 
@@ -109,11 +112,11 @@ def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, co
         src, dst = A, B
         for t in range(K):
             if ids[t] is not None:
-                apply_stencil(stencil, src, dst, ids=ids[t], coeff=coeff, stream=main)
+                apply_stencil(stencil, src, dst, ids=ids[t], coeff=coeff, stream=main, kpaired=lists.kpaired)
             src, dst = dst, src
         if comm is not None and ids is lists.inner:
             main.wait_event(ev1)
     for t in range(K, S):   # sweeps K+1..S whole; src/dst continue the ping-pong (sweep t+1 reads what sweep t wrote)
-        apply_stencil(stencil, src, dst, ids=full.domain if t == S - 1 else full.all, coeff=coeff, stream=main)
+        apply_stencil(stencil, src, dst, ids=full.domain if t == S - 1 else full.all, coeff=coeff, stream=main, kpaired=full.kpaired)
         src, dst = dst, src
     return S

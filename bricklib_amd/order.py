@@ -84,13 +84,14 @@ def _box(grid, lo, hi):
     return grid[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
 
 
-def shell_list(g, lo, hi, ilo, ihi, rows_per_block=8):
+def shell_list(g, lo, hi, ilo, ihi, rows_per_block=8, kpair=False):
     """Tiled list of the bricks of box [lo,hi) of the logical grid `g` that are outside box [ilo,ihi): two k-slabs in the
-    per-XCD slab order, the four j/i side walls row by row."""
+    per-XCD slab order, the four j/i side walls row by row (kpair: the slabs in the k-paired order; the walls stay plain
+    rows, which a k-paired sweep computes as unpaired entries)."""
     if any(ihi[a] <= ilo[a] for a in range(3)):
-        return tiled(_box(g, lo, hi), rows_per_block)
-    klo = slabs(_box(g, lo, [hi[0], hi[1], ilo[2]]), rows_per_block)
-    khi = slabs(_box(g, [lo[0], lo[1], ihi[2]], hi), rows_per_block)
+        return tiled(_box(g, lo, hi), rows_per_block, kpair=kpair)
+    klo = slabs(_box(g, lo, [hi[0], hi[1], ilo[2]]), rows_per_block, kpair=kpair)
+    khi = slabs(_box(g, [lo[0], lo[1], ihi[2]], hi), rows_per_block, kpair=kpair)
     rest = [_box(g, [lo[0], lo[1], ilo[2]], [hi[0], ilo[1], ihi[2]]),        # j-low / j-high
             _box(g, [lo[0], ihi[1], ilo[2]], [hi[0], hi[1], ihi[2]]),
             _box(g, [lo[0], ilo[1], ilo[2]], [ilo[0], ihi[1], ihi[2]]),      # i-low / i-high
@@ -99,13 +100,14 @@ def shell_list(g, lo, hi, ilo, ihi, rows_per_block=8):
     return assemble(klo, khi, chunks(rest))
 
 
-def decomp_lists(d, rows_per_block=8):
+def decomp_lists(d, rows_per_block=8, kpair=False):
     """Brick lists for the weak/strong sweep schedule of a BrickDecomp `d` (see drivers.weak_cycle), all in the geometric
     (logical-grid) tiled order -- i fastest across ghost / surface / inner bricks alike, so runs of i-neighbours share
     halos whatever their ids are:
     inner   -- [1,sep0): bricks that never read a ghost brick
     shell   -- [sep0,sep2): surface + ghost ring            surface -- [sep0,sep1)
-    all     -- [1,sep2): subdomain + ghost ring             domain  -- [1,sep1): the subdomain itself."""
+    all     -- [1,sep2): subdomain + ghost ring             domain  -- [1,sep1): the subdomain itself.
+    kpair: every list in the k-paired order (for sweeps with apply_stencil(..., kpaired=True): the 25-point star)."""
     g = np.asarray(d.grid).astype(np.uint32)
     T = [g.shape[2], g.shape[1], g.shape[0]]
     gb = d.depth // 8                                   # ghost width in bricks
@@ -113,14 +115,15 @@ def decomp_lists(d, rows_per_block=8):
     lo1, hi1 = [gb] * 3, [T[a] - gb for a in range(3)]
     lo2, hi2 = [2 * gb] * 3, [T[a] - 2 * gb for a in range(3)]
     has_inner = all(hi2[a] > lo2[a] for a in range(3))
-    inner = tiled(_box(g, lo2, hi2), rows_per_block) if has_inner else np.zeros(0, dtype=np.uint32)
+    inner = tiled(_box(g, lo2, hi2), rows_per_block, kpair=kpair) if has_inner else np.zeros(0, dtype=np.uint32)
     assert (inner != LIST_SKIP).sum() == d.sep_pos[0] - 1
-    return {"inner": inner, "shell": shell_list(g, lo0, hi0, lo2, hi2, rows_per_block),
-            "surface": shell_list(g, lo1, hi1, lo2, hi2, rows_per_block),
-            "all": tiled(_box(g, lo0, hi0), rows_per_block), "domain": tiled(_box(g, lo1, hi1), rows_per_block)}
+    return {"inner": inner, "shell": shell_list(g, lo0, hi0, lo2, hi2, rows_per_block, kpair),
+            "surface": shell_list(g, lo1, hi1, lo2, hi2, rows_per_block, kpair),
+            "all": tiled(_box(g, lo0, hi0), rows_per_block, kpair=kpair),
+            "domain": tiled(_box(g, lo1, hi1), rows_per_block, kpair=kpair)}
 
 
-def trapezoid_lists(d, sweeps, rows_per_block=8):
+def trapezoid_lists(d, sweeps, rows_per_block=8, kpair=False):
     """Brick lists for the deep-overlap schedule of drivers.weak_cycle_deep.  With L(b) = distance of brick b from the
     outside of the ghosted grid in bricks (ghost ring: 0, surface: 1, ...), sweep t = 1..sweeps is split into
         inner[t-1] -- bricks with L >= t+1: they depend on nothing the exchange delivers (the dependence cone of the
@@ -137,6 +140,6 @@ def trapezoid_lists(d, sweeps, rows_per_block=8):
         ilo = [t + 1] * 3
         ihi = [T[a] - t - 1 for a in range(3)]
         has = all(ihi[a] > ilo[a] for a in range(3))   # False: the cone has closed, everything waits for the exchange
-        inner.append(tiled(_box(g, ilo, ihi), rows_per_block) if has else np.zeros(0, dtype=np.uint32))
-        shell.append(shell_list(g, lo, hi, ilo, ihi, rows_per_block))
+        inner.append(tiled(_box(g, ilo, ihi), rows_per_block, kpair=kpair) if has else np.zeros(0, dtype=np.uint32))
+        shell.append(shell_list(g, lo, hi, ilo, ihi, rows_per_block, kpair))
     return inner, shell

@@ -176,6 +176,13 @@ def test_weak_cycle_other_section_orders(oracle, dev, order, name, nranks, sched
     _weak_virtual(oracle, dev, name, nranks, (40, 32, 48) if schedule == "deep" else (16, 16, 16), schedule, order=order)
 
 
+@pytest.mark.parametrize("schedule,nranks,dom", [("lists", 1, (16, 16, 16)), ("lists", 8, (24, 40, 16)), ("deep", 2, (40, 32, 48))])
+def test_weak_cycle_kpaired_lists_25pt(oracle, dev, schedule, nranks, dom):
+    """the weak cycle of the 25-point star over sweep lists in the k-paired order (SweepLists / TrapezoidLists with kpair=True: two
+    bricks per wave, k_star_kp) -- inner box, shell slabs and walls, shrinking boxes of the deep schedule, odd level counts"""
+    _weak_virtual(oracle, dev, "mpi25pt", nranks, dom, schedule, kpair=True)
+
+
 @pytest.mark.parametrize("schedule,nranks", [("lists", 1), ("lists", 8), ("ranges", 2), ("deep", 4)])
 def test_weak_cycle_fused_double_sweeps(oracle, dev, schedule, nranks):
     """the weak cycle with BRK_MPI7_X2 (4 fused passes = the 8 sweeps of mpi7pt between two exchanges) against the global
@@ -201,7 +208,7 @@ def test_weak_cycle_vs_reference_run_under_mpi(oracle, golden, dev, name, st, nr
                   ref={r: z[f"out_{st}_{nranks}_{r}"] for r in range(nranks)})
 
 
-def _weak_virtual(oracle, dev, name, nranks, dom, schedule, seed=11, ncycles=2, ref=None, order="good"):
+def _weak_virtual(oracle, dev, name, nranks, dom, schedule, seed=11, ncycles=2, ref=None, order="good", kpair=False):
     cart = bl.dims_create(nranks)
     gdims = [cart[2 - a] * dom[a] for a in range(3)]
     d = bl.BrickDecomp(dom, order=order)
@@ -222,7 +229,8 @@ def _weak_virtual(oracle, dev, name, nranks, dom, schedule, seed=11, ncycles=2, 
     table = LinkTable(links, dev)
     S = bl.stencil_iters(name)
     from bricklib_amd.drivers import SweepLists, TrapezoidLists, weak_cycle_deep
-    lists = {"lists": lambda: SweepLists(d, dev), "ranges": lambda: None, "deep": lambda: TrapezoidLists(d, S, dev)}[schedule]()
+    lists = {"lists": lambda: SweepLists(d, dev, kpair=kpair), "ranges": lambda: None,
+             "deep": lambda: TrapezoidLists(d, S, dev, kpair=kpair)}[schedule]()
     if schedule == "deep":
         assert lists.inner[0] is not None
     for _ in range(ncycles):

@@ -387,3 +387,25 @@ def test_host_bookkeeping_under_address_and_ub_sanitizers(tmp_path):
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=300)
     out = r.stdout.decode()
     assert r.returncode == 0 and "probe_asan_host: ok" in out and "ERROR" not in out and "runtime error" not in out, out
+
+
+@pytest.mark.parametrize("dims", [(64, 64, 64), (32, 48, 64), (24, 32, 40)])
+def test_kpaired_sweep_lists_hold_the_same_bricks(dims):
+    """order.decomp_lists / trapezoid_lists with kpair=True (the order brk_stencil_apply_list_kpaired wants): the same brick sets as
+    the plain tiled lists, every list a whole number of 8-entry groups, and inside the full boxes entry w+4 of a group is the +k
+    neighbour of entry w"""
+    from bricklib_amd.decomp import BrickDecomp
+    from bricklib_amd.order import LIST_SKIP, decomp_lists, trapezoid_lists
+    d = BrickDecomp(dims, 8)
+    a, b = decomp_lists(d), decomp_lists(d, kpair=True)
+    for k in a:
+        assert np.array_equal(np.sort(a[k][a[k] != LIST_SKIP]), np.sort(b[k][b[k] != LIST_SKIP])), k
+        assert b[k].size % 8 == 0
+    ia, sa = trapezoid_lists(d, 4)
+    ib, sb = trapezoid_lists(d, 4, kpair=True)
+    for u, v in zip(ia + sa, ib + sb):
+        assert np.array_equal(np.sort(u[u != LIST_SKIP]), np.sort(v[v != LIST_SKIP]))
+    g = b["all"].reshape(-1, 2, 4)
+    both = (g[:, 0, :] != LIST_SKIP) & (g[:, 1, :] != LIST_SKIP)
+    up = d.adj.reshape(-1, 27)[g[:, 0, :][both], 13 + 9]
+    assert both.any() and np.array_equal(up, g[:, 1, :][both])
