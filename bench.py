@@ -49,6 +49,10 @@ def parse():
                          "(default at N>1); strong = fixed global --strong-dom^3 cut into --strong-sub^3 subdomains (config 5)")
     ap.add_argument("--strong-dom", type=int, default=1024)
     ap.add_argument("--strong-sub", type=int, default=128)
+    ap.add_argument("--strong-local-ghosts", choices=["aliased", "copied"], default="aliased",
+                    help="strong workload, ghost runs whose source subdomain lives on the same rank: aliased = reached through the "
+                         "adjacency table, neither copied nor swept (default; same subdomain cells bit for bit); copied = device "
+                         "links as in the reference (strong/main.cu:201-208)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-weak-reference", action="store_true", help="single workload: skip the extra (untimed) weak-workload line")
     ap.add_argument("--no-overlap", action="store_true")
@@ -658,7 +662,7 @@ def run_strong(args, bl, dev, rank, world):
     sid = STENCILS[name]
     K = args.steps if args.steps is not None else 10
     W = args.warmup if args.warmup is not None else 2
-    sr = StrongRank(args.strong_dom, args.strong_sub, rank, world, dev)
+    sr = StrongRank(args.strong_dom, args.strong_sub, rank, world, dev, alias_local=args.strong_local_ghosts == "aliased")
     sr.storages[0].dat.uniform_(0.0, 1.0)
     main = torch.cuda.current_stream()
     S = bl.stencil_iters(sid)
@@ -716,6 +720,10 @@ def run_strong(args, bl, dev, rank, world):
            "kernel": "%s sweeps over %d subdomains of %d^3 (+ghost) per rank, one launch per sweep; kernel_ms = step / %d"
                      % (name, sr.nsub, args.strong_sub, S),
            "scaling": "strong", "updates_per_pass": upd, "conservation_rel_drift": drift, "cells_per_gpu": int(local_cells), "subdomains_per_rank": sr.nsub, "remote_bytes_per_rank": sr.bytes_remote,
+           # ghost runs between two subdomains of one rank: reached through the adjacency table ("aliased": neither copied nor swept)
+           # or copied by device links as in the reference ("copied"); bricks per sweep over subdomains + ghost rings vs subdomain bricks
+           "local_ghosts": args.strong_local_ghosts, "local_link_bytes_per_rank": sr.bytes_local,
+           "swept_bricks_per_sweep": sr.swept_bricks, "subdomain_bricks": sr.nsub * (args.strong_sub // 8) ** 3,
            "transport": ("abi" if comm is not None else ("gloo-staged" if args.backend == "gloo" else "torch")) if world > 1 else "device links"}
     if comm is not None:
         torch.cuda.synchronize()
@@ -840,7 +848,8 @@ def main():
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
                        **{k: res[k] for k in ("layout", "form", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift", "transport", "transport_fallback_reason", "exchange_self_check", "messages_per_exchange",
-                                             "per_peer_send_bytes", "per_peer_GBps_exchange_alone", "distinct_gpus", "ranks_seen") if k in res}},
+                                             "per_peer_send_bytes", "per_peer_GBps_exchange_alone", "distinct_gpus", "ranks_seen",
+                                             "local_ghosts", "local_link_bytes_per_rank", "swept_bricks_per_sweep", "subdomain_bricks") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_by_step": ach_step / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],

@@ -80,6 +80,39 @@ def tiled(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True, kpair=False):
     return assemble(slabs(ids3, rows_per_block, nxcd, pad_rows, kpair), nxcd=nxcd)
 
 
+def tiled_scattered(ids, gi, gj, gk, rows_per_block=8, nxcd=NXCD):
+    """The tiled order for bricks given by coordinates instead of a box: `ids` with brick coordinates (gi, gj, gk) in any common
+    frame (several subdomains of one rank in the global frame, holes and duplicates allowed).  Same traversal as slabs(): XCD x gets
+    its slab of j-rows, swept in blocks of <= rows_per_block rows (None: chosen from the row length) over all k with i fastest,
+    left-over rows are cut along k; runs of i-neighbours stay together and a LIST_SKIP entry follows every run whose length is not a multiple of 8."""
+    ids = np.asarray(ids, dtype=np.uint32)
+    if ids.size == 0:
+        return np.zeros(0, dtype=np.uint32)
+    gi, gj, gk = (np.asarray(c, dtype=np.int64) - int(np.min(c)) for c in (gi, gj, gk))
+    J, K = int(gj.max()) + 1, int(gk.max()) + 1
+    if rows_per_block is None:       # a block of rows of one k-plane stays within ~2 MiB (512 bricks), the measured optimum at 512^3
+        rows_per_block = max(1, min(8, 512 // (int(gi.max()) + 1)))
+    base = J // nxcd
+    left = gj >= base * nxcd                                            # the J % nxcd left-over rows (all rows when J < nxcd)
+    slab = np.where(left, (nxcd * (gk + 1) + K - 1) // K - 1, gj // max(base, 1))     # k in [K*x // nxcd, K*(x+1) // nxcd), as slabs()
+    block = np.where(left, J, (gj - slab * base) // rows_per_block)    # left-over rows come after the blocks of the slab
+    o = np.lexsort((gi, gj, gk, block, slab))
+    ids, gi, gj, gk, slab = ids[o], gi[o], gj[o], gk[o], slab[o]
+    cut = np.ones(ids.size, dtype=bool)                                 # entry starts a run
+    cut[1:] = (gi[1:] != gi[:-1] + 1) | (gj[1:] != gj[:-1]) | (gk[1:] != gk[:-1]) | (slab[1:] != slab[:-1])
+    start = np.nonzero(cut)[0]
+    length = np.diff(np.append(start, ids.size))
+    padded = length + (length % 8 != 0)
+    run_off = np.concatenate([[0], np.cumsum(padded)])
+    out = np.full(int(run_off[-1]), LIST_SKIP, dtype=np.uint32)
+    run_of = np.cumsum(cut) - 1
+    out[run_off[run_of] + (np.arange(ids.size) - start[run_of])] = ids
+    run_slab = slab[start]
+    pieces = [out[int(run_off[:-1][run_slab == x].min()):int(run_off[1:][run_slab == x].max())] if (run_slab == x).any()
+              else np.zeros(0, dtype=np.uint32) for x in range(nxcd)]
+    return assemble(pieces, nxcd=nxcd)
+
+
 def _box(grid, lo, hi):
     return grid[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
 

@@ -313,11 +313,44 @@ def test_star7_kernel_variants(oracle, dev, name, variant):
 
 
 @pytest.mark.parametrize("size", [1, 2, 3, 8])
-@pytest.mark.parametrize("name", ["mpi13pt", "mpi7pt"])
-def test_strong_cycle_virtual_ranks(oracle, dev, name, size):
+@pytest.mark.parametrize("name,ghosts", [("mpi13pt", "aliased"), ("mpi13pt", "copied"), ("mpi7pt", "aliased"), ("mpi7pt", "copied")])
+def test_strong_cycle_virtual_ranks(oracle, dev, name, ghosts, size):
     """strong/main.cpp shape: 64^3 global domain, 16^3 subdomains in Z-Morton order over `size` ranks (all on one GPU;
-    per-peer pack -> loopback -> unpack as transport).  Oracle: the global periodic field swept on the CPU."""
-    _strong_virtual(oracle, dev, name, size, 64, 16, 21, 2)
+    per-peer pack -> loopback -> unpack as transport).  Oracle: the global periodic field swept on the CPU.  ghosts: runs between
+    two subdomains of one rank reached through the adjacency table (the default) or copied by device links as in the reference."""
+    _strong_virtual(oracle, dev, name, size, 64, 16, 21, 2, alias_local=ghosts == "aliased")
+
+
+@pytest.mark.parametrize("name,size,dom,sdom", [("mpi13pt", 1, 128, 32), ("mpi13pt", 3, 128, 32), ("mpi25pt", 5, 64, 16), ("mpi125pt", 2, 64, 32)])
+def test_strong_aliased_local_ghosts_bit_identical_to_copied(dev, name, size, dom, sdom):
+    """two strong cycles with the same-rank ghost runs aliased through the adjacency table against the same cycles with those runs
+    copied and swept (the reference's scheme): the subdomain bricks agree BIT for bit on every rank, fewer bricks are swept, and
+    with one rank there is nothing left to exchange"""
+    from bricklib_amd.strong import StrongRank, loopback_transport
+    res = {}
+    for alias in (True, False):
+        ranks = [StrongRank(dom, sdom, r, size, dev, alias_local=alias) for r in range(size)]
+        gen = torch.Generator(device=dev).manual_seed(17)
+        for sr in ranks:
+            sr.storages[0].dat.copy_(torch.rand(sr.storages[0].dat.shape, dtype=torch.float64, device=dev, generator=gen))
+        transport = loopback_transport(ranks)
+        for _ in range(2):
+            for sr in ranks:
+                sr.exchange_begin()
+            for sr in ranks:
+                if sr.peers:
+                    transport(sr)
+            for sr in ranks:
+                sr.exchange_end()
+                sr.sweeps(name)
+        torch.cuda.synchronize()
+        res[alias] = ([sr.storages[0].dat.view(sr.nsub, sr.nb, 512)[:, 1:sr.d.sep_pos[1]].clone() for sr in ranks],
+                      sum(sr.swept_bricks for sr in ranks), sum(sr.bytes_local for sr in ranks))
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    assert res[True][1] < res[False][1] and res[True][2] < res[False][2]      # bytes_local: links + pack + unpack copies
+    if size == 1:
+        assert res[True][1] == (dom // 8) ** 3 and res[True][2] == 0
 
 
 @pytest.mark.parametrize("name,st,size,dom", [("mpi13pt", 13, 1, 32), ("mpi13pt", 13, 3, 32), ("mpi13pt", 13, 8, 32), ("mpi13pt", 13, 5, 64),
@@ -332,9 +365,9 @@ def test_strong_cycle_vs_reference_run_under_mpi(oracle, golden, dev, name, st, 
     _strong_virtual(oracle, dev, name, size, dom, 16, int(z["seed"][0]), 1, ref=ref)
 
 
-def _strong_virtual(oracle, dev, name, size, dom, sdom, seed, ncycles, ref=None):
+def _strong_virtual(oracle, dev, name, size, dom, sdom, seed, ncycles, ref=None, alias_local=True):
     from bricklib_amd.strong import StrongRank, loopback_transport
-    ranks = [StrongRank(dom, sdom, r, size, dev) for r in range(size)]
+    ranks = [StrongRank(dom, sdom, r, size, dev, alias_local=alias_local) for r in range(size)]
     assert sum(sr.nsub for sr in ranks) == (dom // sdom) ** 3
     ext = (sdom + 16,) * 3
     for sr in ranks:
@@ -1136,7 +1169,7 @@ def test_strong_cycle_baseline_shape_512_128(oracle, dev):
         bl.copyToBrick((sub + 16,) * 3, (0,) * 3, (0,) * 3, torch.from_numpy(blk).to(dev), sr.grid_dev, sr.sub_brick(0, q))
     sum0 = float(view[:, 1:sr.d.sep_pos[1]].sum().item())
     assert abs(sum0 - g.sum()) <= 1e-9 * g.sum()
-    sr.exchange(None, torch.cuda.current_stream())      # one rank: every ghost run is a device link
+    sr.exchange(None, torch.cuda.current_stream())      # one rank: every ghost run is aliased to its source brick, nothing moves
     sr.sweeps("mpi13pt")
     torch.cuda.synchronize()
     view = sr.storages[0].dat.view(sr.nsub, sr.nb, 512)

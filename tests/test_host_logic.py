@@ -409,3 +409,115 @@ def test_kpaired_sweep_lists_hold_the_same_bricks(dims):
     both = (g[:, 0, :] != LIST_SKIP) & (g[:, 1, :] != LIST_SKIP)
     up = d.adj.reshape(-1, 27)[g[:, 0, :][both], 13 + 9]
     assert both.any() and np.array_equal(up, g[:, 1, :][both])
+
+
+def _strong_cycle_on_host(oracle, sid, dom, sdom, size, alias_local, seed=5):
+    """the strong cycle of `size` ranks emulated from the host tables alone (strong.strong_tables / strong_lists): numpy storages,
+    copies and messages executed literally, sweeps by the oracle over the lists.  Returns {zmort id: subdomain cells}."""
+    from bricklib_amd.decomp import SP_RECV, SP_SEND, SP_STORAGE, BrickDecomp
+    from bricklib_amd.order import LIST_SKIP
+    from bricklib_amd.strong import partition, strong_lists, strong_tables, zmort_coords
+    subdim = dom // sdom
+    d = BrickDecomp((sdom,) * 3, 8)
+    nb, ext = d.nbricks, (sdom + 16,) * 3
+    grid = np.ascontiguousarray(d.grid.reshape(-1), dtype=np.uint32)
+    ranks = []
+    for rank in range(size):
+        l, r = partition(subdim ** 3, size, rank)
+        copies, msgs, peers, alias = strong_tables(d, l, r, rank, size, subdim, alias_local)
+        adj, list_all, list_domain = strong_lists(d, r - l, alias, 8)
+        st = [np.zeros((r - l) * nb * 512) for _ in range(3)]
+        for m in range(r - l):
+            o = [c * sdom for c in zmort_coords(l + m)]
+            arr = oracle.fill_array_global(ext, [x - 8 for x in o], (dom,) * 3, seed)
+            arr[:8], arr[-8:], arr[:, :8], arr[:, -8:], arr[:, :, :8], arr[:, :, -8:] = (-1e3,) * 6     # ghosts must come from the exchange
+            oracle.copy_to_brick(ext, (0,) * 3, (0,) * 3, arr, grid, st[0][m * nb * 512:(m + 1) * nb * 512], 512)
+        ranks.append(dict(l=l, r=r, copies=copies, msgs=msgs, adj=np.ascontiguousarray(adj), st=st, alias=alias,
+                          all=list_all[list_all != LIST_SKIP], domain=list_domain[list_domain != LIST_SKIP], send={}, recv={}))
+        if alias_local and size == 1:
+            assert not copies and not msgs and np.array_equal(np.sort(ranks[-1]["all"]), np.sort(ranks[-1]["domain"]))
+    S = bl.stencil_iters(sid)
+    for _ in range(2):
+        for R in ranks:                                               # links + pack (phase 0)
+            for m in R["msgs"]:
+                R["send" if m["is_send"] else "recv"][m["peer"]] = np.zeros(m["bytes"] // 8)
+            a = R["st"][0]
+            for c in R["copies"]:
+                if c["phase"] == 0:
+                    src = a[c["src_off"] // 8:(c["src_off"] + c["bytes"]) // 8]
+                    dst = a if c["dst_space"] == SP_STORAGE else R["send"][c["dst_peer"]]
+                    dst[c["dst_off"] // 8:(c["dst_off"] + c["bytes"]) // 8] = src.copy()
+        for rk, R in enumerate(ranks):                                # transport
+            for p, buf in R["send"].items():
+                ranks[p]["recv"][rk][:] = buf
+        for R in ranks:                                               # unpack (phase 1) + sweeps 1<-0; (2<-1; 1<-2)...; 0<-1
+            a = R["st"][0]
+            for c in R["copies"]:
+                if c["phase"] == 1:
+                    assert c["src_space"] == SP_RECV
+                    a[c["dst_off"] // 8:(c["dst_off"] + c["bytes"]) // 8] = R["recv"][c["src_peer"]][c["src_off"] // 8:(c["src_off"] + c["bytes"]) // 8]
+            seq = [(0, 1, "all")] + [(1, 2, "all"), (2, 1, "all")] * (S // 2 - 1) + [(1, 0, "domain")]
+            for s_, t_, which in seq:
+                oracle.brick_stencil(sid, R["adj"], R["st"][s_], R["st"][t_], 512, ids=np.ascontiguousarray(R[which]))
+    out = {}
+    for R in ranks:
+        for m in range(R["r"] - R["l"]):
+            got = np.zeros(ext[::-1])
+            oracle.copy_from_brick((sdom,) * 3, (0,) * 3, (8,) * 3, got, grid, R["st"][0][m * nb * 512:(m + 1) * nb * 512], 512)
+            out[R["l"] + m] = got[8:-8, 8:-8, 8:-8].copy()
+    return out, sum(R["all"].size for R in ranks)
+
+
+@pytest.mark.parametrize("size", [1, 2, 3, 8])
+def test_strong_aliased_local_ghosts_give_identical_cells(oracle, size):
+    """strong.py alias_local: ghost runs whose source subdomain lives on the same rank are reached through the adjacency table
+    instead of being copied and swept.  Two cycles of the 13-point star over 32^3 in 16^3 subdomains on 1, 2, 3 and 8 ranks, all on
+    the host from the plan tables: BIT-identical subdomain cells with and without aliasing, equal to the global periodic field,
+    fewer bricks swept (none of the ghost ring on one rank, all of it on eight)."""
+    from bricklib_amd.strong import zmort_coords
+    sid, dom, sdom = 3, 32, 16                                        # BRK_MPI13
+    plain, n_plain = _strong_cycle_on_host(oracle, sid, dom, sdom, size, False)
+    alias, n_alias = _strong_cycle_on_host(oracle, sid, dom, sdom, size, True)
+    assert sorted(plain) == sorted(alias) == list(range(8))
+    for z in plain:
+        assert np.array_equal(plain[z], alias[z]), z
+    assert n_alias < n_plain if size < 8 else n_alias == n_plain
+    if size == 1:
+        assert n_alias == 8 * 8                                       # 2^3 bricks per subdomain, the ghost rings are gone
+    gext = (dom + 16,) * 3
+    cur = oracle.fill_array_global(gext, (-8,) * 3, (dom,) * 3, 5)
+    S, Rr = bl.stencil_iters(sid), oracle.radius(sid)
+    for _ in range(2):
+        for s_ in range(1, S + 1):
+            nxt = np.zeros_like(cur)
+            oracle.array_stencil(sid, cur, nxt, (s_ * Rr,) * 3, tuple(g - s_ * Rr for g in gext))
+            cur = nxt
+        core = cur[8:-8, 8:-8, 8:-8].copy()
+        cur = np.pad(core, 8, mode="wrap")
+    for z, cells in alias.items():
+        o = [c * sdom for c in zmort_coords(z)]
+        assert np.abs(cells - core[o[2]:o[2] + sdom, o[1]:o[1] + sdom, o[0]:o[0] + sdom]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("shape", [(16, 16, 16), (6, 9, 7), (5, 66, 13), (4, 3, 20), (18, 18, 18)])
+def test_tiled_order_from_coordinates_equals_tiled_order_of_the_box(shape):
+    """order.tiled_scattered (bricks given by coordinates, any order, holes allowed) reproduces order.tiled exactly on a full box,
+    and with holes keeps every kept brick once, in runs of i-neighbours separated by LIST_SKIP"""
+    from bricklib_amd.order import LIST_SKIP, tiled, tiled_scattered
+    nk, nj, ni = shape
+    ids3 = np.arange(1, nk * nj * ni + 1, dtype=np.uint32).reshape(shape)
+    kk, jj, ii = (c.reshape(-1) for c in np.meshgrid(np.arange(nk), np.arange(nj), np.arange(ni), indexing="ij"))
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(ids3.size)
+    assert np.array_equal(tiled_scattered(ids3.reshape(-1)[perm], ii[perm] + 5, jj[perm] - 3, kk[perm]), tiled(ids3))
+    keep = rng.random(ids3.size) < 0.7
+    got = tiled_scattered(ids3.reshape(-1)[keep], ii[keep], jj[keep], kk[keep])
+    real = got[got != LIST_SKIP]
+    assert got.size % 64 == 0 and np.array_equal(np.sort(real), ids3.reshape(-1)[keep])
+    for a, b in zip(got[:-1], got[1:]):          # list neighbours are i-neighbours or separated by a LIST_SKIP / a run of 8n entries
+        if a != LIST_SKIP and b != LIST_SKIP and b != a + 1:
+            pos = int(np.nonzero(got == b)[0][0])
+            run = 0
+            while pos - 1 - run >= 0 and got[pos - 1 - run] != LIST_SKIP and (run == 0 or got[pos - run] == got[pos - 1 - run] + 1):
+                run += 1
+            assert run % 8 == 0, (a, b, run)

@@ -5,6 +5,7 @@
 #   checks [tests|bench|prof|all]   smoke + pytest -m gpu / default bench line / rocprofv3 kernel-trace stats of the same command
 #   evidence <tag>                  end-of-round evidence: default bench line, kernel-trace stats and PMC passes of the same command
 #                                   -> gpurun_out/<tag>/ (bench_default.json, kernel_stats.csv, pmc_summary.txt, pmc_traffic_all.json, ...)
+#   strong                          strong tests + `bench.py --workload strong` with local ghosts aliased / copied + weak 25-pt cycle
 #   kbench <kbench args>            tools/kbench with the arguments given
 #   occ7 | occall | order7 | reg7   kernel experiments with the default library (occupancy padding, traversal order, registered adjacency)
 #   diag7 | reg7d | abl | prio      the same with a diagnostic build (make -C bricklib_amd/csrc EXTRA_HIPFLAGS=-DBRK_DIAG before gpurun)
@@ -71,6 +72,24 @@ checks) shift; checks "$@" ;;
 evidence) shift; evidence "$@" ;;
 kbench) shift; run "$@" 2>&1 | tee gpurun_out/kbench.log ;;
 *) { case "$recipe" in
+
+strong) # strong workload (config 5 on one GPU): ghosts between subdomains of one rank aliased through the adjacency table vs copied
+  timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout=600 -k "strong or kpaired" > gpurun_out/pytest_strong.log 2>&1; rc=$?
+  tail -5 gpurun_out/pytest_strong.log
+  if [ $rc -ne 0 ]; then exit 1; fi
+  for g in aliased copied; do
+    timeout -k 10 400 python bench.py --workload strong --strong-local-ghosts $g --no-cpu-baseline > gpurun_out/strong_$g.json 2> gpurun_out/strong_$g.err; rc=$?
+    if [ $rc -ne 0 ]; then tail -5 gpurun_out/strong_$g.err; exit 1; fi
+    python3 - gpurun_out/strong_$g.json <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])
+print(d['config'].get('local_ghosts'), round(d['value'], 1), d['unit'], 'ms/step', round(d['ms_per_step'], 3), 'swept', d['config'].get('swept_bricks_per_sweep'),
+      'of', d['config'].get('subdomain_bricks'), 'drift', d['config'].get('conservation_rel_drift'))
+PY
+  done
+  timeout -k 10 300 python bench.py --workload weak --stencil mpi25pt --no-cpu-baseline > gpurun_out/weak_25pt.json 2> gpurun_out/weak_25pt.err; rc=$?
+  tail -1 gpurun_out/weak_25pt.json | cut -c1-400
+  ;;
 
 l1slots) # outstanding L1->L2 read requests per TCP in the brick-copy probe (tools/l1probe): latency sum / (kernel cycles x 256)
   export TMPDIR=/tmp
