@@ -3,19 +3,23 @@
 //   global d^3 periodic domain cut into (d/s)^3 subdomains in Z-Morton order, contiguous id ranges per rank (brk_strong_partition,
 //   brk_strong_neighbor = getrank); all subdomains of a rank in ONE storage with a block-diagonal adjacency table, so that a sweep
 //   over every subdomain is one launch (the reference launches a 3-D grid over a table of Brick3D, main.cu:85-99,464-476);
-//   ghost runs whose source subdomain lives on the same rank are device links (RegionLink, main.cu:201-208), the others are packed
+//   ghost runs whose source subdomain lives on the same rank are ALIASED: every adjacency entry that names such a ghost brick is
+//   pointed at the source subdomain's own brick, so these runs are neither copied nor swept (same subdomain cells bit for bit; the
+//   adjacency-table form of the reference's memory-mapped ghost zones, strong/mmap.cu) -- or, with a 4th argument `copy`, device
+//   links as in the reference (RegionLink, main.cu:201-208); the other runs are packed
 //   into one buffer per peer rank: ONE send + ONE recv per peer (brk_xplan_build_tables -> brk_exchange_begin / transport / end).
 // One process plays `size` ranks on one GPU (the transport between them is brk_exchange_loopback -- device copies in message
 // order; with MPI each rank keeps only its own entry and calls brk_exchange_transport on its ncclComm_t instead), runs one
 // brick_func (exchange + ST_ITER sweeps of the 13-point stencil, main.cpp:359-365) and validates every subdomain against the
 // global array swept on the CPU -- the reference's `-v` option.
-//   build: make -C examples strong_hip        run: examples/strong_hip [d=64] [s=16] [ranks=3]
+//   build: make -C examples strong_hip        run: examples/strong_hip [d=64] [s=16] [ranks=3] [alias|copy]
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <map>
+#include <string>
 #include <tuple>
 #include <vector>
 
@@ -56,6 +60,7 @@ struct Rank {
 int main(int argc, char **argv) {
   const long d = argc > 1 ? atol(argv[1]) : 64, s = argc > 2 ? atol(argv[2]) : 16;
   const int size = argc > 3 ? atoi(argv[3]) : 3;
+  const bool alias_local = !(argc > 4 && std::string(argv[4]) == "copy");
   const uint64_t subdim = (uint64_t)(d / s), allsubs = subdim * subdim * subdim;
   if (d % s || s % 8 || (subdim & (subdim - 1)) || size < 1 || (uint64_t)size > allsubs) {
     fprintf(stderr, "need d %% s == 0, s %% 8 == 0, a power of two of subdomains per axis and at most one rank per subdomain\n");
@@ -76,20 +81,6 @@ int main(int argc, char **argv) {
     uint64_t lr[2];
     brk_strong_partition(allsubs, size, r, lr);
     R.l = lr[0], R.r = lr[1], R.nsub = (size_t)(lr[1] - lr[0]);
-    // block-diagonal adjacency: brick b of subdomain m is brick m * nb + b of the rank's storage
-    std::vector<uint32_t> adj((size_t)R.nsub * nb * 27), all, dom;
-    for (size_t m = 0; m < R.nsub; ++m) {
-      for (size_t q = 0; q < (size_t)nb * 27; ++q) adj[m * nb * 27 + q] = (&one.adj[0][0])[q] + (uint32_t)(m * nb);
-      for (uint32_t b = 1; b < bd.sep_pos[2]; ++b) all.push_back((uint32_t)(m * nb) + b);    // domain + ghost bricks
-      for (uint32_t b = 1; b < bd.sep_pos[1]; ++b) dom.push_back((uint32_t)(m * nb) + b);    // the subdomain itself
-    }
-    R.n_all = (uint32_t)all.size(), R.n_domain = (uint32_t)dom.size();
-    gpuCheck(hipMalloc(&R.adj, adj.size() * 4));
-    gpuCheck(hipMemcpy(R.adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
-    gpuCheck(hipMalloc(&R.list_all, all.size() * 4));
-    gpuCheck(hipMemcpy(R.list_all, all.data(), all.size() * 4, hipMemcpyHostToDevice));
-    gpuCheck(hipMalloc(&R.list_domain, dom.size() * 4));
-    gpuCheck(hipMemcpy(R.list_domain, dom.data(), dom.size() * 4, hipMemcpyHostToDevice));
     const size_t elems = R.nsub * nb * 512;
     for (int w = 0; w < 3; ++w) {
       gpuCheck(hipMalloc(&R.st[w], elems * esz));
@@ -116,6 +107,8 @@ int main(int argc, char **argv) {
     // (receiver Z-Morton id, run index), so the buffers need no header
     auto off = [&](size_t m, uint32_t pos) { return (uint64_t)((m * nb + pos) * bbytes); };
     std::vector<brk_xcopy> copies;
+    std::vector<uint32_t> alias(R.nsub * nb); // brick -> the brick that holds its data
+    for (size_t b = 0; b < alias.size(); ++b) alias[b] = (uint32_t)b;
     typedef std::tuple<uint64_t, uint32_t, size_t> Key; // (receiver zmort, run, local subdomain)
     std::map<int, std::vector<Key>> recv, send;
     for (size_t m = 0; m < R.nsub; ++m) {
@@ -124,7 +117,9 @@ int main(int argc, char **argv) {
         int owner = 0, slot = 0;
         // receive side: ghost run q of z comes from the subdomain in direction ghost[q].neighbor
         brk_strong_neighbor(bd.ghost[q].neighbor.set, z, subdim, allsubs, size, &owner, &slot);
-        if (owner == r)
+        if (owner == r && alias_local)
+          for (uint32_t t = 0; t < bd.ghost[q].len; ++t) alias[m * nb + bd.ghost[q].pos + t] = (uint32_t)((size_t)slot * nb + bd.skin[q].pos + t);
+        else if (owner == r)
           copies.push_back(brk_xcopy{0, 0, BRK_SP_STORAGE, BRK_SP_STORAGE, -1, -1, off((size_t)slot, bd.skin[q].pos), off(m, bd.ghost[q].pos),
                                      (uint64_t)bd.ghost[q].len * bbytes});
         else
@@ -160,11 +155,28 @@ int main(int argc, char **argv) {
       if (ro) msgs.push_back(brk_xmsg{0, 0, p, BRK_SP_RECV, 0, ro});
       if (so) msgs.push_back(brk_xmsg{0, 1, p, BRK_SP_SEND, 0, so});
     }
+    // block-diagonal adjacency: brick b of subdomain m is brick m * nb + b of the rank's storage; aliased ghost bricks are replaced
+    // by their sources and left out of the sweep over subdomains + ghost rings
+    std::vector<uint32_t> adj((size_t)R.nsub * nb * 27), all, dom;
+    for (size_t m = 0; m < R.nsub; ++m) {
+      for (size_t q = 0; q < (size_t)nb * 27; ++q) adj[m * nb * 27 + q] = alias[(&one.adj[0][0])[q] + (uint32_t)(m * nb)];
+      for (uint32_t b = 1; b < bd.sep_pos[2]; ++b)
+        if (alias[m * nb + b] == (uint32_t)(m * nb) + b) all.push_back((uint32_t)(m * nb) + b);    // domain + ghost bricks
+      for (uint32_t b = 1; b < bd.sep_pos[1]; ++b) dom.push_back((uint32_t)(m * nb) + b);    // the subdomain itself
+    }
+    R.n_all = (uint32_t)all.size(), R.n_domain = (uint32_t)dom.size();
+    gpuCheck(hipMalloc(&R.adj, adj.size() * 4));
+    gpuCheck(hipMemcpy(R.adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
+    gpuCheck(hipMalloc(&R.list_all, all.size() * 4));
+    gpuCheck(hipMemcpy(R.list_all, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    gpuCheck(hipMalloc(&R.list_domain, dom.size() * 4));
+    gpuCheck(hipMemcpy(R.list_domain, dom.data(), dom.size() * 4, hipMemcpyHostToDevice));
     BK(brk_xplan_build_tables(r, (uint32_t)copies.size(), copies.data(), (uint32_t)msgs.size(), msgs.data(), &R.plan));
     BK(brk_exchange_view_create(R.plan, R.st[0], &R.view));
-    printf("rank %d: subdomains [%llu, %llu), %zu peers, %.2f MB leave the rank per exchange, %.2f MB stay (device links)\n", r,
+    printf("rank %d: subdomains [%llu, %llu), %zu peers, %.2f MB leave the rank per exchange, %.2f MB are copied inside it (links, pack, unpack), "
+           "%u of %u bricks swept per sweep (%s)\n", r,
            (unsigned long long)R.l, (unsigned long long)R.r, peers.size(), brk_xplan_bytes_remote(R.plan) / 1e6,
-           brk_xplan_bytes_local(R.plan) / 1e6);
+           brk_xplan_bytes_local(R.plan) / 1e6, R.n_all, (uint32_t)(R.nsub * (bd.sep_pos[2] - 1)), alias_local ? "local ghosts aliased" : "local ghosts copied");
   }
 
   std::vector<brk_exchange_view *> views;

@@ -194,10 +194,11 @@ def test_cpp_weak_driver_one_process_per_rank_under_mpiexec(flags):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("args", [("64", "16", "3"), ("64", "16", "1"), ("64", "32", "8"), ("128", "32", "5")])
+@pytest.mark.parametrize("args", [("64", "16", "3"), ("64", "16", "1"), ("64", "32", "8"), ("128", "32", "5"), ("64", "16", "3", "copy"), ("64", "16", "1", "copy")])
 def test_cpp_strong_driver_validates(args):
     """examples/strong_hip.cpp: the reference's strong driver shape in C++ over the C ABI -- Z-Morton ownership
-    (brk_strong_partition / brk_strong_neighbor), block-diagonal adjacency, same-rank ghost runs as device links, one packed
+    (brk_strong_partition / brk_strong_neighbor), block-diagonal adjacency, same-rank ghost runs aliased through the adjacency
+    table (default) or copied by device links as in the reference (`copy`), one packed
     message per peer (brk_xplan_build_tables -> brk_exchange_begin / loopback / end), ST_ITER 13-point sweeps over all
     subdomains of a rank in one launch; the driver's own `-v` check (global periodic array swept on the CPU) must say Validated."""
     exe = os.path.join(ROOT, "examples", "strong_hip")

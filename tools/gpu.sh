@@ -74,7 +74,7 @@ kbench) shift; run "$@" 2>&1 | tee gpurun_out/kbench.log ;;
 *) { case "$recipe" in
 
 strong) # strong workload (config 5 on one GPU): ghosts between subdomains of one rank aliased through the adjacency table vs copied
-  timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x --timeout=600 -k "strong or kpaired" > gpurun_out/pytest_strong.log 2>&1; rc=$?
+  timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_cpp_headers.py -m gpu -q -x --timeout=600 -k "strong or kpaired" > gpurun_out/pytest_strong.log 2>&1; rc=$?
   tail -5 gpurun_out/pytest_strong.log
   if [ $rc -ne 0 ]; then exit 1; fi
   for g in aliased copied; do
@@ -87,6 +87,7 @@ print(d['config'].get('local_ghosts'), round(d['value'], 1), d['unit'], 'ms/step
       'of', d['config'].get('subdomain_bricks'), 'drift', d['config'].get('conservation_rel_drift'))
 PY
   done
+  for g in alias copy; do timeout -k 10 200 examples/strong_hip 512 128 1 $g | tail -2; done
   timeout -k 10 300 python bench.py --workload weak --stencil mpi25pt --no-cpu-baseline > gpurun_out/weak_25pt.json 2> gpurun_out/weak_25pt.err; rc=$?
   tail -1 gpurun_out/weak_25pt.json | cut -c1-400
   ;;
