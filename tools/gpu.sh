@@ -178,6 +178,8 @@ regstar) # star kernels (list form) with / without brk_adjacency_register: compa
   for sid in 0 3 4; do run -n 512 -s $sid -S -o 8 -v 0,100 -i 40 -r2 4; done ;;
 regcube) # cube kernels (list form) with / without brk_adjacency_register: rows of the list neighbours replaced by link bits
   for sid in 1 5 7; do run -n 512 -s $sid -S -o 8 -v 0,100 -i 40 -r2 4; done ;;
+orderx2) # fused double 7-point pass (list form): rows per block of the XCD slab order
+  for o in 2 4 8; do run -n 512 -s 7 -S -o $o -v 100 -i 40 -r2 2; done ;;
 reg7)    # 7-point box kernel with / without brk_adjacency_register
   for r in 1 2 3; do run -n 512 -s 0 -S -b -v 0 -i 60; run -n 512 -s 0 -S -b -v 0 -i 60 -R; done ;;
 order7)  # 7-point list form: rows per block of the XCD slab order
