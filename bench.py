@@ -87,7 +87,7 @@ def parse():
                     help="single workload: separate = input and output fields in two storages (step 512, the layout of the "
                          "reference's weak/strong drivers); interleaved = both fields in one storage (step 1024, the layout of "
                          "single/: 3axis.cpp:25-28).  Same kernels; interleaving reads and writes in the same DRAM pages costs "
-                         "1.5 % (7-pt) to 10 % (27-pt) on MI355X (profiles/r01_h_layouts.json)")
+                         "1.5 %% (7-pt) to 10 %% (27-pt) on MI355X (profiles/r01_h_layouts.json)")
     ap.add_argument("--fuse", type=int, default=2, choices=(1, 2),
                     help="weak workload with the 7-point stencil: 2 = every pass over memory performs two of the ST_ITER = 8 sweeps "
                          "between exchanges (BRK_MPI7_X2, the 25-point S*S stencil; results equal to rounding), 1 = one sweep per pass")

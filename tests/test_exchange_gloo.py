@@ -131,3 +131,13 @@ def test_bench_gpus_n_without_gpus_fails_fast():
     if torch.cuda.device_count() >= 2:
         pytest.skip("this host has two GPUs")
     assert r.returncode == 2 and b"needs 2 visible GPUs" in r.stderr and r.stdout.strip() == b""
+
+
+def test_bench_help_lists_every_option():
+    """`python bench.py --help` formats (argparse expands `%` in help strings) and names the options the docs quote"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    for opt in ("--gpus", "--steps", "--warmup", "--workload", "--schedule", "--exchange", "--transport", "--backend", "--strong-local-ghosts"):
+        assert opt in out, opt
