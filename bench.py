@@ -99,6 +99,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--windows", type=int, default=5, help="single workload: the K-step timed region is repeated this many times; the median is reported")
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="single workload: extra steady-state figure over this many seconds of launches (0 = skip)")
+    ap.add_argument("--one-way", action="store_true",
+                    help="every sweep walks the bricks in the same direction. Default: successive sweeps over the same bricks alternate "
+                         "direction (BRK_SWEEP_REVERSE on every other launch: same bricks, same results), so a sweep starts in the part of "
+                         "the field the 256 MB Infinity Cache still holds from the one before; the single workload also reports the "
+                         "one-way kernel time beside it")
     ap.add_argument("--no-config3", action="store_true", help="single workload: skip the 27-/125-/13-/25-point lines on the same grid")
     return ap.parse_args()
 
@@ -177,33 +182,41 @@ def cpu_baseline_reference(n_cells_axis, seconds):
                       f"{points} points per call incl. its ghost zone ({n_cells_axis}^3 useful = useful_value), OpenMP {cores} threads, {dt:.1f} s"}
 
 
-def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, launches=100, nsample=512, warm_ms=150.0):
+def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, launches=100, nsample=512, warm_ms=150.0, zigzag=True):
     """One of the other stencils of BASELINE configs 2-3 on the SAME 512^3 grid through the same box entry point, outside
     the timed headline: kernel time from HIP events on the launch stream, roofline fraction, sampled oracle check."""
     from bricklib_amd.stencils import STENCILS
     sid = STENCILS[name]
     coeff = np.random.default_rng(1).random(129) if name in ("7pt", "27pt") else None
     bIn, bOut = bl.Brick(info, st, 0), bl.Brick(info, sto, off_out)
+    zz = bl.Zigzag()
+
+    def sweep(one_way=False):
+        bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream, reverse=zigzag and not one_way and zz.turn())
+
     # the sampled oracle check of the previous stencil leaves the GPU idle for seconds: warm up until the clocks are back
     # (>= warm_ms of back-to-back launches) before the timed launches
     w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     w0.record(stream)
     for _ in range(20):
-        bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream)
+        sweep()
     w1.record(stream)
     torch.cuda.synchronize()
     for _ in range(int(warm_ms / max(w0.elapsed_time(w1) / 20, 1e-3))):
-        bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sweep()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record(stream)
     for _ in range(launches):
-        bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream)
+        sweep()
     e1.record(stream)
+    for _ in range(launches if zigzag else 0):
+        sweep(one_way=True)
+    e2.record(stream)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / launches
     cells = float(len(ids)) * 512.0
     ach = BYTES_PER_UPDATE * cells / (ms * 1e-3) / 1e9
-    r = {"kernel_ms": ms, "GStencil/s": cells / (ms * 1e-3) / 1e9, "launches": launches,
+    r = {"kernel_ms": ms, "kernel_ms_one_way": e1.elapsed_time(e2) / launches if zigzag else ms, "GStencil/s": cells / (ms * 1e-3) / 1e9, "launches": launches,
          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                       "frac_of_measured_copy": ach / HBM_COPY_GBS}}
     if O is not None:
@@ -303,11 +316,15 @@ def run_single(args, bl, dev):
     NB = SB - 2
     box = (0, (SB, SB, SB), (1, 1, 1), (NB, NB, NB))     # the reference launch: dim3 block(NB,NB,NB), b = grid[GB+z][GB+y][GB+x]
 
-    def step():
+    zz = bl.Zigzag()
+    zigzag = not args.one_way
+
+    def step(one_way=False):
+        rev = zigzag and not one_way and zz.turn()
         if args.form == "box":
-            bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream)
+            bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream, reverse=rev)
         else:
-            bl.apply_stencil(sid, bIn, bOut, ids=ids_dev, coeff=coeff, stream=stream)
+            bl.apply_stencil(sid, bIn, bOut, ids=ids_dev, coeff=coeff, stream=stream, reverse=rev)
 
     cells = float(N) ** 3
     extra = {}
@@ -367,7 +384,21 @@ def run_single(args, bl, dev):
         wins.append((time.perf_counter() - t0, e0.elapsed_time(e1) / K))
     order = sorted(range(len(wins)), key=lambda q: wins[q][0])
     wall, kern_ms = wins[order[len(order) // 2]]
-    res = {"workload": f"single-{name}-{N}" + (f"-variant{args.variant}" if args.variant else ""), "layout": args.layout, "form": args.form, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+    if zigzag:      # the same launches, all in one direction, beside the headline (not part of it)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(W):
+            step(one_way=True)
+        e0.record(stream)
+        for _ in range(max(K, 50)):
+            step(one_way=True)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        one_ms = e0.elapsed_time(e1) / max(K, 50)
+        extra["one_way"] = {"kernel_ms": one_ms, "value": cells / (one_ms * 1e-3) / 1e9, "unit": "GStencil/s",
+                            "roofline_frac": BYTES_PER_UPDATE * cells / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "what": "every launch walks the bricks in the same direction (--one-way); the headline alternates the direction of "
+                                    "successive sweeps (BRK_SWEEP_REVERSE), which lets a sweep start in what the Infinity Cache still holds"}
+    res = {"workload": f"single-{name}-{N}" + (f"-variant{args.variant}" if args.variant else ""), "layout": args.layout, "form": args.form, "sweep_direction": "alternating" if zigzag else "one way", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
            "kernel": "%s over %d bricks" % ("k_s7_wg<8 waves>" if name in ("7pt", "mpi7pt") else ("k_star_wg" if name in ("mpi13pt", "mpi25pt") else "k_cube_dense"), ids.size)}
     extra["timing"] = {"protocol": "%s%d warm-up steps, then the median of %d windows of %d launches, each between two device synchronisations"
@@ -385,7 +416,7 @@ def run_single(args, bl, dev):
         blk = {}
         for nm in ("27pt", "mpi125pt", "mpi13pt", "mpi25pt"):
             if nm != name:
-                blk[nm] = side_stencil(bl, O, nm, info, st, sto, step_e, off_out, ids, box, stream)
+                blk[nm] = side_stencil(bl, O, nm, info, st, sto, step_e, off_out, ids, box, stream, zigzag=zigzag)
         try:      # HBM-side traffic per launch of these kernels from the committed PMC passes (static, like roofline.traffic)
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_by_stencil.json")))
             for nm in blk:
@@ -556,12 +587,12 @@ def run_weak(args, bl, dev, rank, world):
         deep_depth = S if not deep_depth else max(1, min(deep_depth, S))
 
         def step():
-            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=xstream, depth=deep_depth, full=whole)
+            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=xstream, depth=deep_depth, full=whole, zigzag=not args.one_way)
     else:
         lists = SweepLists(d, dev, kpair=kp)
 
         def step():
-            return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=xstream, overlap=overlap, lists=lists, state=state)
+            return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=xstream, overlap=overlap, lists=lists, state=state, zigzag=not args.one_way)
 
     # sustained clocks before the contract's W warm-up cycles + K timed cycles: >= 0.25 s of plain sweeps A -> B (no communication;
     # A is not written, B is scratch between cycles).  With the driver's --steps 20 the timed region is 40 ms; straight after the
@@ -688,7 +719,7 @@ def run_strong(args, bl, dev, rank, world):
 
     def step():
         sr.exchange(transport, main)
-        sr.sweeps(sid, stream=main)
+        sr.sweeps(sid, stream=main, zigzag=not args.one_way)
 
     for _ in range(W):
         step()
@@ -847,7 +878,7 @@ def main():
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
-                       **{k: res[k] for k in ("layout", "form", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
+                       **{k: res[k] for k in ("layout", "form", "sweep_direction", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift", "transport", "transport_fallback_reason", "exchange_self_check", "messages_per_exchange",
                                              "per_peer_send_bytes", "per_peer_GBps_exchange_alone", "distinct_gpus", "ranks_seen",
                                              "local_ghosts", "local_link_bytes_per_rank", "swept_bricks_per_sweep", "subdomain_bricks") if k in res}},

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   __shared__ uint32_t breaks[NW];
   __shared__ double jslot[KIND == kCube125 && PIPE == 5 ? NW * 192 : 1]; // output-side shift slots, one per wave
   const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + wg_in_xcd(cf, per_xcd);
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t slot = wg * NW + w;
   const int lane = threadIdx.x & 63;

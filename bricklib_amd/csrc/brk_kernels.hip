@@ -216,7 +216,7 @@ int link_mask(const uint32_t *adj, hipStream_t st, const uint32_t **out);
 int face_table(const uint32_t *adj, hipStream_t st, const uint32_t **out);
 
 int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                   uint32_t first, uint32_t n, const double *coeff_host, brk_stream s, bool kpaired = false) {
+                   uint32_t first, uint32_t n, const double *coeff_host, brk_stream s, bool kpaired = false, bool reverse = false) {
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
   if (!adj || !in || !out) return brk_fail(BRK_EINVAL, "null device pointer");
   if (in == out) return brk_fail(BRK_EINVAL, "in and out must be different fields");
@@ -227,6 +227,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   const int var = g_variant[id].load(std::memory_order_relaxed);
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
+  cf.reverse = reverse ? 1u : 0u;
   hipStream_t st = static_cast<hipStream_t>(s);
   const uint32_t *lmask = nullptr, *faces = nullptr;
   if (id == BRK_27PT_COEFF || id == BRK_MPI125 || id == BRK_MPI7_X2 || id == BRK_7PT_X2) {
@@ -628,6 +629,20 @@ extern "C" int brk_stencil_apply_list_kpaired(int id, const uint32_t *adj, const
   return launch_stencil(id, adj, in, out, step, ids, 0, n, coeff_host, s, true);
 }
 
+extern "C" int brk_stencil_apply_range_ex(int id, const uint32_t *adj, const double *in, double *out, size_t step, uint32_t begin,
+                                          uint32_t end, const double *coeff_host, uint32_t flags, brk_stream s) {
+  if (flags & ~(uint32_t)BRK_SWEEP_REVERSE) return brk_fail(BRK_EINVAL, "brk_stencil_apply_range_ex: flags %#x (only BRK_SWEEP_REVERSE applies to a range)", flags);
+  if (end < begin) return brk_fail(BRK_EINVAL, "brick range [%u,%u) is reversed", begin, end);
+  return launch_stencil(id, adj, in, out, step, nullptr, begin, end - begin, coeff_host, s, false, (flags & BRK_SWEEP_REVERSE) != 0);
+}
+
+extern "C" int brk_stencil_apply_list_ex(int id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
+                                         uint32_t n, const double *coeff_host, uint32_t flags, brk_stream s) {
+  if (flags & ~(uint32_t)(BRK_SWEEP_KPAIRED | BRK_SWEEP_REVERSE)) return brk_fail(BRK_EINVAL, "brk_stencil_apply_list_ex: unknown flags %#x", flags);
+  if (n && !ids) return brk_fail(BRK_EINVAL, "null brick id list");
+  return launch_stencil(id, adj, in, out, step, ids, 0, n, coeff_host, s, (flags & BRK_SWEEP_KPAIRED) != 0, (flags & BRK_SWEEP_REVERSE) != 0);
+}
+
 extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                                       uint32_t first, uint32_t n, uint32_t ntaps, const int32_t *offsets_host,
                                       const double *weights_host, brk_stream s) {
@@ -661,6 +676,14 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
 extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *in, double *out, size_t step,
                                      uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3],
                                      const double *coeff_host, brk_stream s) {
+  return brk_stencil_apply_box_ex(id, adj, in, out, step, base, tot, lo, cnt, coeff_host, 0u, s);
+}
+
+extern "C" int brk_stencil_apply_box_ex(int id, const uint32_t *adj, const double *in, double *out, size_t step,
+                                        uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3],
+                                        const double *coeff_host, uint32_t flags, brk_stream s) {
+  if (flags & ~(uint32_t)BRK_SWEEP_REVERSE) return brk_fail(BRK_EINVAL, "brk_stencil_apply_box_ex: flags %#x (only BRK_SWEEP_REVERSE applies to a box)", flags);
+  const bool reverse = (flags & BRK_SWEEP_REVERSE) != 0;
   if (!tot || !lo || !cnt) return brk_fail(BRK_EINVAL, "null box geometry");
   for (int a = 0; a < 3; ++a)
     if (lo[a] + cnt[a] > tot[a]) return brk_fail(BRK_EINVAL, "box exceeds the grid on axis %d", a);
@@ -671,6 +694,7 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
   if ((uint64_t)cnt[0] * cnt[1] * cnt[2] == 0) return BRK_OK;
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
+  cf.reverse = reverse ? 1u : 0u;
   if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) {
     const uint32_t *regmask = nullptr, *faces = nullptr; // registered adjacency: bricks whose face neighbours are the predicted ones skip their rows
     if (int rc = regular_mask(adj, tot[0], tot[0] * tot[1], static_cast<hipStream_t>(s), &regmask)) return rc;
@@ -686,7 +710,7 @@ extern "C" int brk_stencil_apply_box(int id, const uint32_t *adj, const double *
   // Infinity Cache and are not what bounds the kernel, the shorter rows-in-flight window is (profiles/r03_d_25pt_rows_per_block.txt).
   const bool kpair = id == BRK_MPI25; // the radius-4 star runs two bricks per wave over k-paired lists (k_star_kp, brk_starwg.hip)
   if (int rc = box_list_locked(base, tot, lo, cnt, 8u, kpair, &e)) return rc;
-  if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s, kpair)) return rc;
+  if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s, kpair, reverse)) return rc;
   HIP_TRY(hipEventRecord(e->last_use, static_cast<hipStream_t>(s)));
   return BRK_OK;
 }

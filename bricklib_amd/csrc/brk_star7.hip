@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
                                                                       const uint32_t *__restrict__ faces) {
   __shared__ double lds[NW * kTile];
   const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + wg_in_xcd(cf, per_xcd);
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t slot = wg * NW + w;
   const int lane = threadIdx.x & 63;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
   if (MODE == kModeBox) {
     static_assert(MODE != kModeBox || NW == 8, "box mode walks rows in groups of 8");
     uint32_t slab_edge = 0;
-    active = box_entry(bx, blockIdx.x & 7u, blockIdx.x >> 3, w, b, has_prev, has_next, DIAG ? &slab_edge : nullptr);
+    active = box_entry(bx, blockIdx.x & 7u, wg_in_xcd(cf, per_xcd), w, b, has_prev, has_next, DIAG ? &slab_edge : nullptr);
     b = __builtin_amdgcn_readfirstlane(b);
     if (DIAG) diag_edge = __builtin_amdgcn_readfirstlane(slab_edge);
     b_prev = b - 1;

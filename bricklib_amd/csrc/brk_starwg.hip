@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_star_wg(
   using TL = WgTile<R>;
   __shared__ double lds[NW * TL::TILE];
   const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + wg_in_xcd(cf, per_xcd);
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t slot = wg * NW + w;
   const int lane = threadIdx.x & 63;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, OCC) void k_star_kp(
   typedef const __attribute__((address_space(1))) d2 *gc2;
   __shared__ double lds[NW * TL::TILE];
   const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + wg_in_xcd(cf, per_xcd);
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int hi = lane >> 3, lo = lane & 7;

@@ -11,7 +11,7 @@ import torch
 
 from .brick import grid_to_device
 from .order import decomp_lists, trapezoid_lists
-from .stencils import apply_stencil, stencil_iters
+from .stencils import Zigzag, apply_stencil, stencil_iters
 
 
 class SweepLists:
@@ -25,24 +25,28 @@ class SweepLists:
             setattr(self, name, grid_to_device(ids, device))
 
 
-def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, overlap=True, lists=None, state=None):
+def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, overlap=True, lists=None, state=None, zigzag=True):
     """A, B: Brick objects over two storages built from decomposition `d`; exchange(stream) refreshes A's ghosts.
     main/comm: torch streams (default: current stream, no overlap).  lists: SweepLists(d) (optional; without it the
     sweeps run over plain id ranges).  state: dict carried from one cycle to the next (optional): the last sweep writes
     the surface bricks first and records an event, so that the NEXT cycle's exchange can start while the inner bricks
     of the last sweep -- and then of the first sweep -- are still being computed (the exchange only reads surface bricks
-    of A and writes ghost bricks of A, which the last sweep neither writes nor reads)."""
+    of A and writes ghost bricks of A, which the last sweep neither writes nor reads).
+    zigzag: successive sweeps walk their bricks in alternating directions (BRK_SWEEP_REVERSE): a sweep reads what the one before
+    wrote, and starts with what it wrote last -- the part the Infinity Cache still holds.  Same results."""
     S = stencil_iters(stencil)
     sep0, sep1, sep2 = d.sep_pos
     main = main or torch.cuda.current_stream()
+    zz = Zigzag()
 
     def sweep(src, dst, which):
+        rev = zigzag and zz.turn()
         if lists is not None:
-            apply_stencil(stencil, src, dst, ids=getattr(lists, which), coeff=coeff, stream=main, kpaired=lists.kpaired)
+            apply_stencil(stencil, src, dst, ids=getattr(lists, which), coeff=coeff, stream=main, kpaired=lists.kpaired, reverse=rev)
         else:
             rng = {"inner": (1, sep0), "shell": (sep0, sep2), "surface": (sep0, sep1), "all": (1, sep2),
                    "domain": (1, sep1)}[which]
-            apply_stencil(stencil, src, dst, brick_range=rng, coeff=coeff, stream=main)
+            apply_stencil(stencil, src, dst, brick_range=rng, coeff=coeff, stream=main, reverse=rev)
 
     if comm is None or not overlap:
         exchange(main)
@@ -83,7 +87,7 @@ class TrapezoidLists:
         self.shell = [grid_to_device(x, device) if x.size else None for x in shell]
 
 
-def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, comm=None, depth=None, full=None):
+def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, comm=None, depth=None, full=None, zigzag=True):
     """Same result as weak_cycle, scheduled so that the exchange hides behind most of the cycle instead of one sweep
     (xGMI is a per-link-bound point-to-point fabric; a 512^3 subdomain sends 104 MB per exchange).  While the ghosts
     of A travel on `comm`, `main` runs the part of EVERY sweep that cannot depend on them yet -- sweep t over the bricks
@@ -99,6 +103,7 @@ def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, co
     K = S if depth is None else max(1, min(int(depth), S))
     assert K == S or full is not None, "depth < ST_ITER needs the whole-sweep lists (full=SweepLists(d))"
     main = main or torch.cuda.current_stream()
+    zz = Zigzag()
     if comm is None:
         exchange(main)
     else:
@@ -112,11 +117,12 @@ def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, co
         src, dst = A, B
         for t in range(K):
             if ids[t] is not None:
-                apply_stencil(stencil, src, dst, ids=ids[t], coeff=coeff, stream=main, kpaired=lists.kpaired)
+                apply_stencil(stencil, src, dst, ids=ids[t], coeff=coeff, stream=main, kpaired=lists.kpaired, reverse=zigzag and zz.turn())
             src, dst = dst, src
         if comm is not None and ids is lists.inner:
             main.wait_event(ev1)
     for t in range(K, S):   # sweeps K+1..S whole; src/dst continue the ping-pong (sweep t+1 reads what sweep t wrote)
-        apply_stencil(stencil, src, dst, ids=full.domain if t == S - 1 else full.all, coeff=coeff, stream=main, kpaired=full.kpaired)
+        apply_stencil(stencil, src, dst, ids=full.domain if t == S - 1 else full.all, coeff=coeff, stream=main, kpaired=full.kpaired,
+                      reverse=zigzag and zz.turn())
         src, dst = dst, src
     return S

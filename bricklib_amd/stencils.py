@@ -3,7 +3,8 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (BRK_7PT_COEFF, BRK_27PT_COEFF, BRK_MPI7, BRK_MPI13, BRK_MPI25, BRK_MPI125, check, lib)
+from ._lib import (BRK_7PT_COEFF, BRK_27PT_COEFF, BRK_MPI7, BRK_MPI13, BRK_MPI25, BRK_MPI125, BRK_SWEEP_KPAIRED, BRK_SWEEP_REVERSE, check,
+                   lib)
 from .brick import _ptr, _stream
 
 # name -> id; names follow the reference's stencil scripts (stencils/*.py) and drivers
@@ -26,30 +27,44 @@ def stencil_iters(stencil):
     return lib.brk_stencil_iters(_sid(stencil))
 
 
-def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coeff=None, stream=None, kpaired=False):
+def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coeff=None, stream=None, kpaired=False, reverse=False):
     """out[b] = stencil(in[b], neighbours) for b in `ids` (device int32 tensor holding uint32 brick ids, e.g.
     the reference's `grid`), in brick_range=(begin,end), or in box=(base, tot[3], lo[3], cnt[3]) of a lexicographic
     numbering (contiguous axis first).  bIn/bOut: Brick objects sharing one BrickInfo.  kpaired: `ids` is in the k-paired
-    order of bricklib_amd.order.tiled(..., kpair=True) (brk_stencil_apply_list_kpaired: faster for the 25-point star, same results)."""
+    order of bricklib_amd.order.tiled(..., kpair=True) (BRK_SWEEP_KPAIRED: faster for the 25-point star, same results).
+    reverse: walk the same bricks back to front (BRK_SWEEP_REVERSE); alternate it from one sweep to the next and the sweep starts
+    where the last one stopped -- in the part of the field the Infinity Cache still holds (class Zigzag below)."""
     sid = _sid(stencil)
     cp = None
     if coeff is not None:
         cbuf = np.ascontiguousarray(coeff, dtype=np.float64)
         cp = cbuf.ctypes.data_as(C.POINTER(C.c_double))
     adj = bIn.bInfo.adj
+    flags = (BRK_SWEEP_KPAIRED if kpaired and ids is not None and box is None else 0) | (BRK_SWEEP_REVERSE if reverse else 0)
     if box is not None:
         base, tot, lo, cnt = box
         U3 = C.c_uint32 * 3
-        check(lib.brk_stencil_apply_box(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, int(base),
-                                        U3(*[int(x) for x in tot]), U3(*[int(x) for x in lo]), U3(*[int(x) for x in cnt]),
-                                        cp, _stream(stream)))
+        check(lib.brk_stencil_apply_box_ex(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, int(base),
+                                           U3(*[int(x) for x in tot]), U3(*[int(x) for x in lo]), U3(*[int(x) for x in cnt]),
+                                           cp, flags, _stream(stream)))
     elif ids is not None:
-        check((lib.brk_stencil_apply_list_kpaired if kpaired else lib.brk_stencil_apply_list)(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids),
-                                         ids.numel(), cp, _stream(stream)))
+        check(lib.brk_stencil_apply_list_ex(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids), ids.numel(), cp, flags,
+                                            _stream(stream)))
     else:
         b0, b1 = brick_range if brick_range is not None else (0, bIn.bInfo.nbricks)
-        check(lib.brk_stencil_apply_range(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, int(b0), int(b1), cp,
-                                          _stream(stream)))
+        check(lib.brk_stencil_apply_range_ex(sid, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, int(b0), int(b1), cp, flags,
+                                             _stream(stream)))
+
+
+class Zigzag:
+    """Direction of successive sweeps over the same bricks: `z.turn()` returns False, True, False, ... -- pass it as `reverse=`."""
+
+    def __init__(self):
+        self.reverse = True
+
+    def turn(self):
+        self.reverse = not self.reverse
+        return self.reverse
 
 
 def apply_taps(taps, bIn, bOut, ids=None, brick_range=None, stream=None):

@@ -26,7 +26,7 @@ from ._lib import check, lib
 from .brick import Brick, BrickInfo, BrickStorage, grid_to_device
 from .decomp import SP_RECV, SP_SEND, SP_STORAGE, BrickDecomp, Exchanger, XPlan, exchange_loopback
 from .order import LIST_SKIP, decomp_lists, tiled_scattered
-from .stencils import apply_stencil, stencil_iters
+from .stencils import Zigzag, apply_stencil, stencil_iters
 
 
 def zmort_coords(zid):
@@ -173,15 +173,18 @@ class StrongRank:
             transport(self, stream)
         self.exchange_end(stream)
 
-    def sweeps(self, stencil, coeff=None, stream=None):
-        """strong/main.cpp:359-365: 1<-0; (2<-1; 1<-2) x (S/2-1); 0<-1 without the outer brick ring."""
+    def sweeps(self, stencil, coeff=None, stream=None, zigzag=True):
+        """strong/main.cpp:359-365: 1<-0; (2<-1; 1<-2) x (S/2-1); 0<-1 without the outer brick ring.  zigzag: successive sweeps walk
+        the lists in alternating directions (a sweep starts with what the one before wrote last), see drivers.weak_cycle."""
         S = stencil_iters(stencil)
         b = self.bricks
-        apply_stencil(stencil, b[0], b[1], ids=self.list_all, coeff=coeff, stream=stream)
+        zz = Zigzag()
+        rev = lambda: zigzag and zz.turn()
+        apply_stencil(stencil, b[0], b[1], ids=self.list_all, coeff=coeff, stream=stream, reverse=rev())
         for _ in range(S // 2 - 1):
-            apply_stencil(stencil, b[1], b[2], ids=self.list_all, coeff=coeff, stream=stream)
-            apply_stencil(stencil, b[2], b[1], ids=self.list_all, coeff=coeff, stream=stream)
-        apply_stencil(stencil, b[1], b[0], ids=self.list_domain, coeff=coeff, stream=stream)
+            apply_stencil(stencil, b[1], b[2], ids=self.list_all, coeff=coeff, stream=stream, reverse=rev())
+            apply_stencil(stencil, b[2], b[1], ids=self.list_all, coeff=coeff, stream=stream, reverse=rev())
+        apply_stencil(stencil, b[1], b[0], ids=self.list_domain, coeff=coeff, stream=stream, reverse=rev())
         return S
 
 

@@ -16,9 +16,19 @@
 
 namespace brk {
 
+// per-launch parameters every kernel receives by value: the stencil's coefficients and the direction of the sweep
 struct Coeffs {
   double c[32];
+  // 1: every XCD walks its share of the list / box from the END (workgroup g of the share takes the place of workgroup
+  // per_xcd-1-g).  Same bricks, same results; a sweep that starts where the previous one stopped finds the part of the field
+  // touched last still in the 256 MB Infinity Cache (brk_stencil_apply_*_ex, BRK_SWEEP_REVERSE)
+  uint32_t reverse;
 };
+// index of this workgroup inside its XCD's share of a launch of 8 * per_xcd workgroups
+__device__ __forceinline__ uint32_t wg_in_xcd(const Coeffs &cf, uint32_t per_xcd) {
+  const uint32_t g = blockIdx.x >> 3;
+  return cf.reverse ? per_xcd - 1u - g : g;
+}
 
 // adjacency slot of direction (dk,dj,di), include/brick.h:237-245 of the reference
 __host__ __device__ constexpr int adj_slot(int dk, int dj, int di) { return (dk + 1) * 9 + (dj + 1) * 3 + (di + 1); }

@@ -60,7 +60,8 @@ enum { BRK_7PT_COEFF = 0, BRK_27PT_COEFF = 1, BRK_MPI7 = 2, BRK_MPI13 = 3, BRK_M
 
 const char *brk_last_error(void);
 /* version of this ABI: 1000 + additions (1001: brk_stencil_apply_taps, 1002: the fused double-sweep stencil ids,
- * 1003: the ghost-zone exchange: brk_xplan_*, brk_exchange_*, brk_comm_*; 1004: brk_adjacency_register / _release) */
+ * 1003: the ghost-zone exchange: brk_xplan_*, brk_exchange_*, brk_comm_*; 1004: brk_adjacency_register / _release;
+ * 1005: brk_stencil_apply_{range,list,box}_ex with BRK_SWEEP_* flags) */
 int brk_abi_version(void);
 /* radius / number of coefficients / communication-avoiding sweeps per exchange (ST_ITER, fake.h:39-344) */
 int brk_stencil_radius(int stencil_id);
@@ -105,6 +106,28 @@ int brk_stencil_apply_list_kpaired(int stencil_id, const uint32_t *adj_dev, cons
 int brk_stencil_apply_box(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
                           size_t step_elems, uint32_t base, const uint32_t tot_bricks[3], const uint32_t lo[3],
                           const uint32_t cnt[3], const double *coeff_host, brk_stream s);
+
+/* The three forms above with sweep flags:
+ *   BRK_SWEEP_KPAIRED  (list form) the list is in the k-paired order, see brk_stencil_apply_list_kpaired.
+ *   BRK_SWEEP_REVERSE  walk the same bricks from the other end: every XCD takes its share of the range / list / box back to front
+ *                      (workgroups keep their 4 or 8 consecutive entries).  Results do not depend on it.  An iterative solver calls
+ *                      the sweep again and again over the same bricks (the reference's timing loops, stencils/3axis.hip.cpp:168-190,
+ *                      weak/main.cu:246-287): when sweep t+1 starts where sweep t stopped, the part of the field touched last
+ *                      -- up to the 256 MB of the Infinity Cache -- is read from that cache instead of HBM.  Alternate the flag
+ *                      from one sweep to the next: 7-point 512^3 sweep 0.376 -> 0.363 ms, 13-point 0.395 -> 0.379, fused double
+ *                      7-point pass 0.443 -> 0.425 (profiles/r03_l_zigzag_sweeps.txt).
+ * Unknown flag bits, or BRK_SWEEP_KPAIRED on a range or box: BRK_EINVAL. */
+#define BRK_SWEEP_KPAIRED 1u
+#define BRK_SWEEP_REVERSE 2u
+int brk_stencil_apply_range_ex(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
+                               size_t step_elems, uint32_t brick_begin, uint32_t brick_end, const double *coeff_host,
+                               uint32_t flags, brk_stream s);
+int brk_stencil_apply_list_ex(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
+                              size_t step_elems, const uint32_t *brick_ids_dev, uint32_t n, const double *coeff_host,
+                              uint32_t flags, brk_stream s);
+int brk_stencil_apply_box_ex(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
+                             size_t step_elems, uint32_t base, const uint32_t tot_bricks[3], const uint32_t lo[3],
+                             const uint32_t cnt[3], const double *coeff_host, uint32_t flags, brk_stream s);
 
 /* OPTIONAL promise about an adjacency table: from brk_adjacency_register(adj_dev, nbricks) until brk_adjacency_release(adj_dev)
  * the nbricks x 27 entries at adj_dev (current device) do not change.  The library may then keep derived tables next to it; so

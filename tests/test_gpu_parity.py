@@ -524,6 +524,47 @@ def test_box_form(oracle, dev, name, shape):
     assert np.abs(got - want.reshape(-1, 512)).max() <= TOL
 
 
+@pytest.mark.parametrize("name", ["7pt", "mpi7pt", "cond", "mpi13pt", "mpi25pt", "27pt", "mpi125pt", "mpi7pt_x2"])
+def test_reversed_sweeps_are_bit_identical(oracle, dev, name):
+    """BRK_SWEEP_REVERSE (apply_stencil(reverse=True): every XCD walks its share of the launch back to front): box, list (tiled,
+    k-paired, ragged with skipped entries) and range forms give the same bits as the forward sweep and the oracle's result; unknown
+    flag bits and a k-paired box are refused."""
+    import ctypes as C
+    from bricklib_amd._lib import lib
+    from bricklib_amd.order import tiled
+    shape = (13, 21, 7)
+    ni, nj, nk = shape
+    grid, info = bl.init_grid(shape, dev)
+    st = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    st.dat.uniform_(0.0, 1.0)
+    coeff = oracle.coeffs(129, 1) if name in ("7pt", "27pt", "cond") else None
+    g3 = grid.reshape(nk, nj, ni)[1:-1, 1:-1, 1:-1]
+    flat = np.ascontiguousarray(g3).reshape(-1)
+    forms = {"box": dict(box=(0, shape, (1, 1, 1), (ni - 2, nj - 2, nk - 2))), "tiled": dict(ids=grid_to_device(tiled(g3), dev)),
+             "kpaired": dict(ids=grid_to_device(tiled(g3, kpair=True), dev), kpaired=True), "ragged": dict(ids=grid_to_device(flat[1:-3:3].copy(), dev)),
+             "range": dict(brick_range=(int(flat.min()), int(flat.max()) + 1))}
+    bIn = bl.Brick(info, st, 0)
+    for fname, kw in forms.items():
+        out = {}
+        for rev in (False, True):
+            so = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+            bl.apply_stencil(name, bIn, bl.Brick(info, so, 0), coeff=coeff, reverse=rev, **kw)
+            out[rev] = so.dat.clone()
+        assert torch.equal(out[False], out[True]), (name, fname)
+        if fname in ("box", "tiled", "kpaired") and name in NAMES:
+            hin = st.dat.cpu().numpy()
+            want = np.zeros_like(hin)
+            oracle.brick_stencil(NAMES[name], info.adj_host, hin, want, 512, ids=flat, coeff=coeff)
+            assert np.abs(out[True].cpu().numpy() - want).max() <= TOL, (name, fname)
+    U3 = C.c_uint32 * 3
+    so = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    args = (bl.STENCILS[name], info.adj.data_ptr(), st.dat.data_ptr(), so.dat.data_ptr(), 512)
+    cp = None if coeff is None else np.ascontiguousarray(coeff).ctypes.data_as(C.POINTER(C.c_double))
+    assert lib.brk_stencil_apply_box_ex(*args, 0, U3(*shape), U3(1, 1, 1), U3(ni - 2, nj - 2, nk - 2), cp, 1, None) != 0        # k-paired box
+    assert lib.brk_stencil_apply_list_ex(*args, forms["tiled"]["ids"].data_ptr(), 8, cp, 4, None) != 0                           # unknown bit
+    assert lib.brk_stencil_apply_range_ex(*args, 1, 2, cp, 1, None) != 0                                                         # k-paired range
+
+
 def test_box_form_decomp_inner(oracle, dev):
     """inner region [1,sep0) of a BrickDecomp as a box (base 1)"""
     d = bl.BrickDecomp((48, 40, 56))

@@ -20,7 +20,7 @@ def test_abi_symbols_exported():
     L = C.CDLL(LIB_PATH)
     for s in ABI_SYMBOLS:
         assert hasattr(L, s), s
-    assert lib.brk_abi_version() == 1004
+    assert lib.brk_abi_version() == 1005
 
 
 def test_error_convention():

@@ -180,6 +180,23 @@ regcube) # cube kernels (list form) with / without brk_adjacency_register: rows 
   for sid in 1 5 7; do run -n 512 -s $sid -S -o 8 -v 0,100 -i 40 -r2 4; done ;;
 orderx2) # fused double 7-point pass (list form): rows per block of the XCD slab order
   for o in 2 4 8; do run -n 512 -s 7 -S -o $o -v 100 -i 40 -r2 2; done ;;
+zigzag)  # every other sweep walks the bricks backwards (what the last sweep touched last is read first: Infinity-Cache reuse)
+  for sid in 0 3 7; do run -n 512 -s $sid -S -o 8 -v 100 -i 60 -r2 2; run -n 512 -s $sid -S -o 8 -v 100 -i 60 -r2 2 -Z; done
+  for w in "" "--one-way"; do
+    timeout -k 10 300 python bench.py --no-cpu-baseline $w > gpurun_out/zz_single$w.json 2> gpurun_out/zz_single$w.err || { tail -5 gpurun_out/zz_single$w.err; exit 1; }
+    timeout -k 10 300 python bench.py --workload weak --no-cpu-baseline --no-scaling-base $w > gpurun_out/zz_weak$w.json 2> gpurun_out/zz_weak$w.err || { tail -5 gpurun_out/zz_weak$w.err; exit 1; }
+    timeout -k 10 400 python bench.py --workload strong --no-cpu-baseline $w > gpurun_out/zz_strong$w.json 2> gpurun_out/zz_strong$w.err || { tail -5 gpurun_out/zz_strong$w.err; exit 1; }
+    python3 - "$w" <<'PY'
+import json, sys
+w = sys.argv[1]
+for k in ("single", "weak", "strong"):
+    d = json.loads([l for l in open(f"gpurun_out/zz_{k}{w}.json") if l.startswith("{")][-1])
+    extra = ""
+    if k == "single":
+        extra = " one_way %s | " % (d.get("one_way") or {}).get("kernel_ms") + " ".join("%s %.4f/%.4f" % (n, v["kernel_ms"], v.get("kernel_ms_one_way", 0)) for n, v in d.get("config3", {}).items() if isinstance(v, dict))
+    print(w or "alternating", k, round(d["value"], 1), d["unit"], "ms/step", round(d["ms_per_step"], 4), "frac", round(d["roofline"]["frac"], 4), extra)
+PY
+  done ;;
 reg7)    # 7-point box kernel with / without brk_adjacency_register
   for r in 1 2 3; do run -n 512 -s 0 -S -b -v 0 -i 60; run -n 512 -s 0 -S -b -v 0 -i 60 -R; done ;;
 order7)  # 7-point list form: rows per block of the XCD slab order

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_stream2_persist(const double *in, doubl
 
 int main(int argc, char **argv) {
   int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1, rounds = 2;
-  bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false, reg = false, kpair = false;
+  bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false, reg = false, kpair = false, zigzag = false;
   std::vector<int> variants = {1, 2, 5};
   for (int a = 1; a < argc; ++a) {
     std::string o = argv[a];
@@ -175,6 +175,7 @@ int main(int argc, char **argv) {
     else if (o == "-k") kstack = atoi(argv[++a]); // with -o: workgroup = 8 i-bricks x kstack k-levels
     else if (o == "-P") kpair = true;      // with -o: k-paired order -- runs of 4 i-neighbours at k followed by the same run at k+1 (k_star_kp)
     else if (o == "-R") reg = true;        // brk_adjacency_register: the table is promised immutable
+    else if (o == "-Z") zigzag = true;     // list form: every other launch walks each XCD's share of the list backwards (groups of 8 kept)
     else if (o == "-c") stream = true;     // also run the streaming-ceiling kernels
     else if (o == "-D") {                  // diagnostic builds of libbrk.so: timing experiment of the 7-point box kernel
       typedef void (*diag_fn)(int);
@@ -266,10 +267,21 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&res_d, 8));
   CK(hipMemcpy(adj_d, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
   if (reg) BK(brk_adjacency_register(adj_d, nbricks));
+  uint32_t *rids_d = nullptr;
   if (!ids.empty()) {
     CK(hipMalloc(&ids_d, ids.size() * 4));
     CK(hipMemcpy(ids_d, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+    if (zigzag && ids.size() % 64 == 0) { // the same bricks, each XCD's eighth walked from its end (what was touched last is touched first)
+      std::vector<uint32_t> r(ids.size());
+      const size_t per = ids.size() / 8, groups = per / 8;
+      for (size_t x = 0; x < 8; ++x)
+        for (size_t g = 0; g < groups; ++g)
+          for (size_t e = 0; e < 8; ++e) r[x * per + g * 8 + e] = ids[x * per + (groups - 1 - g) * 8 + e];
+      CK(hipMalloc(&rids_d, r.size() * 4));
+      CK(hipMemcpy(rids_d, r.data(), r.size() * 4, hipMemcpyHostToDevice));
+    }
   }
+  unsigned long launches = 0;
   k_fill<<<4096, 256>>>(st_in, elems, 1);
   CK(hipMemset(st_ref, 0, elems * 8));
   CK(hipDeviceSynchronize());
@@ -283,7 +295,7 @@ int main(int argc, char **argv) {
       uint32_t SBu = (uint32_t)(N / 8 + 2), tot[3] = {SBu, SBu, SBu}, lo3[3] = {1, 1, 1}, cnt[3] = {SBu - 2, SBu - 2, SBu - 2};
       BK(brk_stencil_apply_box(sid, adj_d, st_in, out, step, 0, tot, lo3, cnt, cp, nullptr));
     } else if (ids_d)
-      BK(brk_stencil_apply_list(sid, adj_d, st_in, out, step, ids_d, nlist, cp, nullptr));
+      BK(brk_stencil_apply_list(sid, adj_d, st_in, out, step, (rids_d && (launches++ & 1)) ? rids_d : ids_d, nlist, cp, nullptr));
     else
       BK(brk_stencil_apply_range(sid, adj_d, st_in, out, step, first, first + nlist, cp, nullptr));
   };
