@@ -104,6 +104,8 @@ def parse():
                          "direction (BRK_SWEEP_REVERSE on every other launch: same bricks, same results), so a sweep starts in the part of "
                          "the field the 256 MB Infinity Cache still holds from the one before; the single workload also reports the "
                          "one-way kernel time beside it")
+    ap.add_argument("--weak-zigzag", action="store_true", help="weak workload: alternate the direction of successive sweeps too (no gain measured: "
+                                                                "a ping-pong sweep reads what the previous one wrote with non-temporal stores)")
     ap.add_argument("--no-config3", action="store_true", help="single workload: skip the 27-/125-/13-/25-point lines on the same grid")
     return ap.parse_args()
 
@@ -587,12 +589,12 @@ def run_weak(args, bl, dev, rank, world):
         deep_depth = S if not deep_depth else max(1, min(deep_depth, S))
 
         def step():
-            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=xstream, depth=deep_depth, full=whole, zigzag=not args.one_way)
+            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=xstream, depth=deep_depth, full=whole, zigzag=args.weak_zigzag)
     else:
         lists = SweepLists(d, dev, kpair=kp)
 
         def step():
-            return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=xstream, overlap=overlap, lists=lists, state=state, zigzag=not args.one_way)
+            return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=xstream, overlap=overlap, lists=lists, state=state, zigzag=args.weak_zigzag)
 
     # sustained clocks before the contract's W warm-up cycles + K timed cycles: >= 0.25 s of plain sweeps A -> B (no communication;
     # A is not written, B is scratch between cycles).  With the driver's --steps 20 the timed region is 40 ms; straight after the
