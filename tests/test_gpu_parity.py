@@ -1054,7 +1054,13 @@ def test_bench_line_contract_small():
     assert d["max_abs_err_vs_oracle"] <= TOL
     for nm in ("27pt", "mpi125pt", "mpi13pt", "mpi25pt"):
         assert d["config3"][nm]["max_abs_err_vs_oracle"] <= TOL and d["config3"][nm]["roofline"]["frac"] > 0
+        assert d["config3"][nm]["kernel_ms_one_way"] > 0
     assert d["weak_workload_on_this_gpu"]["value"] > 0
+    # round 3: successive sweeps alternate direction by default; the one-way launches are timed beside the headline
+    assert d["config"]["sweep_direction"] == "alternating" and d["one_way"]["kernel_ms"] > 0 and d["one_way"]["value"] > 0
+    one, _ = _bench_line(["--cells", "64", "--steps", "3", "--warmup", "1", "--windows", "1", "--steady-seconds", "0", "--no-cpu-baseline", "--no-config3",
+                          "--no-weak-reference", "--one-way"])
+    assert one["config"]["sweep_direction"] == "one way" and "one_way" not in one
 
 
 def _bench_line(args, timeout=560):
