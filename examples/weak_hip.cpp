@@ -120,5 +120,6 @@ int main(int argc, char **argv) {
   }
   free(bInfo.adj);
   std::cout << (ok ? "weak_hip: all exchanges match" : "weak_hip: FAILED") << std::endl;
-  return ok ? 0 : 1;
+  fflush(stdout); // everything of ours is released: leave without the HIP / OpenMP runtimes' exit-time destructors (see strong_hip.cpp)
+  _Exit(ok ? 0 : 1);
 }
