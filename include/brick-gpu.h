@@ -65,6 +65,14 @@ inline void brkReleaseAdjacency(const BrickInfo<dims> &bInfo_dev) {
   (void)brk_adjacency_release(reinterpret_cast<const uint32_t *>(bInfo_dev.adj));
 }
 
+// OPTIONAL (not in the reference): direction of successive sweeps over the same bricks.  `brkSweepTurn t; ... brk_stencil_apply_box_ex(...,
+// t.flags(), stream)` inside the timed lambda walks the bricks forwards, backwards, forwards, ...: a sweep then starts in the part of
+// the field the Infinity Cache still holds from the one before (brk.h, BRK_SWEEP_REVERSE; results do not depend on it).
+struct brkSweepTurn {
+  unsigned turn = 0;
+  uint32_t flags() { return (turn++ & 1u) ? BRK_SWEEP_REVERSE : 0u; }
+};
+
 // new BrickStorage on the destination side holding a copy of the data
 inline BrickStorage movBrickStorage(BrickStorage &bStorage, gpuMemcpyKind kind) {
   assert(kind == gpuMemcpyHostToDevice || kind == gpuMemcpyDeviceToHost);
