@@ -294,6 +294,8 @@ def run_single(args, bl, dev):
     sid = STENCILS[name]
     if args.variant:
         from bricklib_amd._lib import check, lib
+        if not hasattr(lib, "brk_set_variant"):
+            raise SystemExit("--variant needs a development build of libbrk.so (make -C bricklib_amd/csrc VARIANTS=1)")
         check(lib.brk_set_variant(sid, args.variant))
     K = args.steps if args.steps is not None else 200
     W = args.warmup if args.warmup is not None else 20

@@ -48,7 +48,8 @@ def _load():
     L.brk_stencil_apply_box_ex.argtypes = [C.c_int, vp, vp, vp, C.c_size_t, C.c_uint32, U3, U3, U3, f64p, C.c_uint32, vp]
     L.brk_stencil_apply_taps.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_int32), f64p, vp]
-    L.brk_set_variant.argtypes = [C.c_int, C.c_int]
+    if hasattr(L, "brk_set_variant"):      # development builds only (make DEV=1 / VARIANTS=1): not part of the product ABI
+        L.brk_set_variant.argtypes = [C.c_int, C.c_int]
     L.brk_link_copy.argtypes = [vp, C.c_uint32, C.c_uint64, vp]
     L.brk_array_to_brick.argtypes = [L3, L3, L3, vp, vp, vp, C.c_size_t, vp]
     L.brk_brick_to_array.argtypes = [L3, L3, L3, vp, vp, vp, C.c_size_t, vp]
@@ -137,7 +138,7 @@ lib = _load()
 # every symbol include/brk.h declares (tests check the library exports each of them)
 ABI_SYMBOLS = [
     "brk_last_error", "brk_abi_version", "brk_stencil_radius", "brk_stencil_ncoeff", "brk_stencil_iters",
-    "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_stencil_apply_list_kpaired", "brk_stencil_apply_box", "brk_stencil_apply_range_ex", "brk_stencil_apply_list_ex", "brk_stencil_apply_box_ex", "brk_stencil_apply_taps", "brk_set_variant", "brk_link_copy", "brk_array_to_brick",
+    "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_stencil_apply_list_kpaired", "brk_stencil_apply_box", "brk_stencil_apply_range_ex", "brk_stencil_apply_list_ex", "brk_stencil_apply_box_ex", "brk_stencil_apply_taps", "brk_link_copy", "brk_array_to_brick",
     "brk_brick_to_array", "brk_compare_brick", "brk_init_grid", "brk_decomp_build", "brk_decomp_free",
     "brk_decomp_nbricks", "brk_decomp_grid_size", "brk_decomp_tdims", "brk_decomp_sep_pos", "brk_decomp_grid",
     "brk_decomp_adj", "brk_decomp_nruns", "brk_decomp_ghost", "brk_decomp_skin", "brk_decomp_nskin",

@@ -10,9 +10,15 @@
 
 namespace brk {
 
-// development knob (tools/kbench -L): unused dynamic LDS added to every stencil launch -> fewer workgroups resident per CU
+#ifdef BRK_DEV_KNOBS
+// development builds only (make DEV=1): unused dynamic LDS added to every stencil launch -> fewer workgroups resident per CU
+// (tools/kbench -L), and which timing experiment the diagnostic kernels run (-DBRK_DIAG, tools/kbench -D)
 extern size_t g_pad_lds;
-extern int g_diag; // diagnostic builds (-DBRK_DIAG): which timing experiment the 7-point box kernel runs (tools/kbench -D)
+extern int g_diag;
+#else
+constexpr size_t g_pad_lds = 0; // release launches carry no dynamic LDS
+constexpr int g_diag = 0;
+#endif
 
 constexpr int kWavesPerWG = 4;
 constexpr int kWG = 64 * kWavesPerWG;

@@ -157,9 +157,11 @@ __global__ __launch_bounds__(kWG) void k_iter(IterGeom g, double *__restrict__ a
   }
 }
 
-// experiment knob (brk_set_variant): read once per launch; atomic so that a concurrent setter is not a data race, but a
-// process that changes variants while other threads launch gets either kernel -- documented as not thread-safe in brk.h
+#ifdef BRK_DEV_KNOBS
+// experiment knob (brk_set_variant, development builds only): read once per launch; atomic so that a concurrent setter is not a
+// data race, but a process that changes variants while other threads launch gets either kernel
 std::atomic<int> g_variant[BRK_NSTENCIL];
+#endif
 constexpr int kDefaultStar7Variant = 5; // 8-wave workgroups sharing i-faces through LDS (brk_star7.hip)
 
 // defaults: stencils/fake.h:11-33
@@ -210,10 +212,15 @@ int make_coeffs(int id, const double *host, Coeffs &cf) {
   return BRK_OK;
 }
 
-// registered adjacency tables (defined further down): per brick, is it linked to its -i / +i neighbour (see k_link_mask)?
-int link_mask(const uint32_t *adj, hipStream_t st, const uint32_t **out);
+// registered adjacency tables (defined further down).  Lifetime rule: a launch path takes g_adj_mutex BEFORE it looks a derived
+// table up and keeps it until the kernel that reads the table has been enqueued; brk_adjacency_release takes the same mutex and
+// then frees with hipFree, which waits for enqueued work -- so a release from another thread can never free a table between
+// the lookup and the launch.  The *_locked functions expect the caller to hold the mutex.
+std::mutex g_adj_mutex;
+// per brick, is it linked to its -i / +i neighbour (see k_link_mask)?
+int link_mask_locked(const uint32_t *adj, const uint32_t **out);
 // ... and the six face neighbours of every brick as one aligned 32-byte row (see k_face_table)
-int face_table(const uint32_t *adj, hipStream_t st, const uint32_t **out);
+int face_table_locked(const uint32_t *adj, const uint32_t **out);
 
 int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const double *coeff_host, brk_stream s, bool kpaired = false, bool reverse = false) {
@@ -224,16 +231,21 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   // the kernels move halo rows and columns in 16-byte lanes
   if (((uintptr_t)in | (uintptr_t)out) % 16 || step % 2) return brk_fail(BRK_EINVAL, "brick fields must be 16-byte aligned (in %p, out %p, step_elems %zu)", (const void *)in, (void *)out, step);
   if (n == 0) return BRK_OK;
+#ifdef BRK_DEV_KNOBS
   const int var = g_variant[id].load(std::memory_order_relaxed);
+#else
+  const int var = 0;
+#endif
   Coeffs cf;
   if (int rc = make_coeffs(id, coeff_host, cf)) return rc;
   cf.reverse = reverse ? 1u : 0u;
   hipStream_t st = static_cast<hipStream_t>(s);
   const uint32_t *lmask = nullptr, *faces = nullptr;
+  std::lock_guard<std::mutex> adj_lock(g_adj_mutex); // held until the launch below is enqueued (see the lifetime rule above)
   if (id == BRK_27PT_COEFF || id == BRK_MPI125 || id == BRK_MPI7_X2 || id == BRK_7PT_X2) {
-    if (int rc = link_mask(adj, st, &lmask)) return rc; // cube kernels over a registered table: the rows of the list neighbours need not be read
+    if (int rc = link_mask_locked(adj, &lmask)) return rc; // cube kernels over a registered table: the rows of the list neighbours need not be read
   } else {
-    if (int rc = face_table(adj, st, &faces)) return rc; // star kernels over a registered table: one 32-byte row of face ids instead of a 108-byte row
+    if (int rc = face_table_locked(adj, &faces)) return rc; // star kernels over a registered table: one 32-byte row of face ids instead of a 108-byte row
   }
   // default kernels: 7-point family in brk_star7.hip, 13-/25-point in brk_starwg.hip, 27-/125-point and the fused double
   // 7-point sweep in brk_cubedense.hip.  Builds with -DBRK_VARIANTS also carry the earlier generations (brk_set_variant).
@@ -297,6 +309,8 @@ int make_geom(const long dimlist[3], const long padding[3], const long ghost[3],
 
 } // namespace
 
+#ifdef BRK_DEV_KNOBS
+// development builds only (make DEV=1 / VARIANTS=1 / EXTRA_HIPFLAGS=-DBRK_DIAG; tools/kbench): not part of the product ABI
 namespace brk {
 size_t g_pad_lds = 0;
 int g_diag = 0;
@@ -312,6 +326,7 @@ extern "C" int brk_set_variant(int id, int v) {
   g_variant[id] = v;
   return BRK_OK;
 }
+#endif
 
 // Id list of a structured box in the traversal order of bricklib_amd/order.py (per-XCD slabs of j-rows swept over all k,
 // left-over rows cut along k, one skipped entry behind rows that are not a multiple of 8, XCD parts padded to equal length).
@@ -495,106 +510,112 @@ struct AdjEntry {
   const uint32_t *adj;
   uint32_t nbricks;
   int device;
-  std::vector<std::pair<std::pair<uint32_t, uint32_t>, uint32_t *>> masks; // (s1, s2) -> device bit mask
-  uint32_t *linkmask = nullptr;                                             // k_link_mask, built on first use
-  uint32_t *faces = nullptr;                                                // k_face_table, built on first use
+  struct Mask {
+    uint32_t s1, s2;
+    uint32_t *dev;
+    uint64_t stamp;
+  };
+  std::vector<Mask> masks;      // (s1, s2) -> device bit mask, at most kMaxMasks of them (least recently used one replaced)
+  uint32_t *linkmask = nullptr; // k_link_mask, built by brk_adjacency_register
+  uint32_t *faces = nullptr;    // k_face_table, built by brk_adjacency_register
 };
-std::mutex g_adj_mutex;
+constexpr size_t kMaxMasks = 8;
+uint64_t g_mask_clock = 0;
 std::vector<AdjEntry> g_adj;
 
-// the face-regularity mask of a registered table for id strides (s1, s2), built on first use (that call is synchronous on `st`);
-// nullptr (and BRK_OK) when the table is not registered
-int regular_mask(const uint32_t *adj, uint32_t s1, uint32_t s2, hipStream_t st, const uint32_t **out) {
-  *out = nullptr;
-  std::lock_guard<std::mutex> lock(g_adj_mutex);
-  for (AdjEntry &e : g_adj) {
-    if (e.adj != adj) continue;
-    for (auto &m : e.masks)
-      if (m.first.first == s1 && m.first.second == s2) {
-        *out = m.second;
-        return BRK_OK;
-      }
-    int device = 0;
-    HIP_TRY(hipGetDevice(&device));
-    if (device != e.device) return brk_fail(BRK_EINVAL, "adjacency table registered on device %d used on device %d", e.device, device);
-    const uint32_t words = 2 * ((e.nbricks + 255) / 256 * 4);
-    uint32_t *mask = nullptr;
-    HIP_TRY(hipMalloc(&mask, (size_t)words * sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_regular_mask, dim3((e.nbricks + 255) / 256), dim3(256), 0, st, adj, e.nbricks, s1, s2, mask);
-    hipError_t r = hipGetLastError();
-    if (r == hipSuccess) r = hipStreamSynchronize(st);
-    if (r != hipSuccess) {
-      (void)hipFree(mask);
-      HIP_TRY(r);
-    }
-    e.masks.push_back({{s1, s2}, mask});
-    *out = mask;
-    return BRK_OK;
-  }
+void free_entry(AdjEntry &e) { // hipFree waits for the kernels that still read a table
+  for (auto &m : e.masks) (void)hipFree(m.dev);
+  if (e.linkmask) (void)hipFree(e.linkmask);
+  if (e.faces) (void)hipFree(e.faces);
+  e.masks.clear();
+  e.linkmask = e.faces = nullptr;
+}
+
+AdjEntry *find_locked(const uint32_t *adj) {
+  for (AdjEntry &e : g_adj)
+    if (e.adj == adj) return &e;
+  return nullptr;
+}
+
+int same_device(const AdjEntry &e) {
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  if (device != e.device) return brk_fail(BRK_EINVAL, "adjacency table registered on device %d used on device %d", e.device, device);
   return BRK_OK;
 }
 
-int face_table(const uint32_t *adj, hipStream_t st, const uint32_t **out) {
+// the face-regularity mask of a registered table for id strides (s1, s2), built on first use of that pair (that one call is
+// synchronous on `st`: the strides are a property of the launch, not of the table); nullptr (and BRK_OK) when the table is not
+// registered.  Caller holds g_adj_mutex.
+int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, hipStream_t st, const uint32_t **out) {
   *out = nullptr;
-  std::lock_guard<std::mutex> lock(g_adj_mutex);
-  for (AdjEntry &e : g_adj) {
-    if (e.adj != adj) continue;
-    if (!e.faces) {
-      int device = 0;
-      HIP_TRY(hipGetDevice(&device));
-      if (device != e.device) return brk_fail(BRK_EINVAL, "adjacency table registered on device %d used on device %d", e.device, device);
-      uint32_t *t = nullptr;
-      HIP_TRY(hipMalloc(&t, (size_t)e.nbricks * 8 * sizeof(uint32_t)));
-      hipLaunchKernelGGL(k_face_table, dim3((e.nbricks + 255) / 256), dim3(256), 0, st, adj, e.nbricks, t);
-      hipError_t r = hipGetLastError();
-      if (r == hipSuccess) r = hipStreamSynchronize(st); // the first call for a table is synchronous
-      if (r != hipSuccess) {
-        (void)hipFree(t);
-        HIP_TRY(r);
-      }
-      e.faces = t;
+  AdjEntry *e = find_locked(adj);
+  if (!e) return BRK_OK;
+  for (auto &m : e->masks)
+    if (m.s1 == s1 && m.s2 == s2) {
+      m.stamp = ++g_mask_clock;
+      *out = m.dev;
+      return BRK_OK;
     }
-    *out = e.faces;
-    return BRK_OK;
+  if (int rc = same_device(*e)) return rc;
+  const uint32_t words = 2 * ((e->nbricks + 255) / 256 * 4);
+  uint32_t *mask = nullptr;
+  HIP_TRY(hipMalloc(&mask, (size_t)words * sizeof(uint32_t)));
+  hipLaunchKernelGGL(k_regular_mask, dim3((e->nbricks + 255) / 256), dim3(256), 0, st, adj, e->nbricks, s1, s2, mask);
+  hipError_t r = hipGetLastError();
+  if (r == hipSuccess) r = hipStreamSynchronize(st);
+  if (r != hipSuccess) {
+    (void)hipFree(mask);
+    HIP_TRY(r);
   }
+  if (e->masks.size() >= kMaxMasks) { // bounded: the least recently used pair of strides goes (hipFree waits for its readers)
+    size_t victim = 0;
+    for (size_t q = 1; q < e->masks.size(); ++q)
+      if (e->masks[q].stamp < e->masks[victim].stamp) victim = q;
+    (void)hipFree(e->masks[victim].dev);
+    e->masks.erase(e->masks.begin() + victim);
+  }
+  e->masks.push_back({s1, s2, mask, ++g_mask_clock});
+  *out = mask;
   return BRK_OK;
 }
 
-int link_mask(const uint32_t *adj, hipStream_t st, const uint32_t **out) {
-  *out = nullptr;
-  std::lock_guard<std::mutex> lock(g_adj_mutex);
-  for (AdjEntry &e : g_adj) {
-    if (e.adj != adj) continue;
-    if (!e.linkmask) {
-      int device = 0;
-      HIP_TRY(hipGetDevice(&device));
-      if (device != e.device) return brk_fail(BRK_EINVAL, "adjacency table registered on device %d used on device %d", e.device, device);
-      uint32_t *mask = nullptr;
-      HIP_TRY(hipMalloc(&mask, (size_t)((e.nbricks + 255) / 256) * 16 * sizeof(uint32_t)));
-      hipLaunchKernelGGL(k_link_mask, dim3((e.nbricks + 255) / 256), dim3(256), 0, st, adj, e.nbricks, mask);
-      hipError_t r = hipGetLastError();
-      if (r == hipSuccess) r = hipStreamSynchronize(st); // the first call for a table is synchronous
-      if (r != hipSuccess) {
-        (void)hipFree(mask);
-        HIP_TRY(r);
-      }
-      e.linkmask = mask;
-    }
-    *out = e.linkmask;
-    return BRK_OK;
-  }
-  return BRK_OK;
+int face_table_locked(const uint32_t *adj, const uint32_t **out) {
+  const AdjEntry *e = find_locked(adj);
+  *out = e ? e->faces : nullptr;
+  return e ? same_device(*e) : BRK_OK;
+}
+
+int link_mask_locked(const uint32_t *adj, const uint32_t **out) {
+  const AdjEntry *e = find_locked(adj);
+  *out = e ? e->linkmask : nullptr;
+  return e ? same_device(*e) : BRK_OK;
 }
 } // namespace
 
+// The two derived tables that depend on the adjacency alone are built HERE (setup time, null stream, synchronous), so that the
+// launch paths never allocate or synchronise for them: usable under stream capture and from several streams at once.
 extern "C" int brk_adjacency_register(const uint32_t *adj_dev, uint32_t nbricks) {
   if (!adj_dev || nbricks == 0) return brk_fail(BRK_EINVAL, "brk_adjacency_register: null table / no bricks");
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(g_adj_mutex);
-  for (const AdjEntry &e : g_adj)
-    if (e.adj == adj_dev) return brk_fail(BRK_EINVAL, "brk_adjacency_register: table %p is registered already", (const void *)adj_dev);
-  g_adj.push_back(AdjEntry{adj_dev, nbricks, device, {}, nullptr, nullptr});
+  if (find_locked(adj_dev)) return brk_fail(BRK_EINVAL, "brk_adjacency_register: table %p is registered already", (const void *)adj_dev);
+  AdjEntry e{adj_dev, nbricks, device, {}, nullptr, nullptr};
+  const dim3 grid((nbricks + 255) / 256), block(256);
+  hipError_t r = hipMalloc(&e.faces, (size_t)nbricks * 8 * sizeof(uint32_t));
+  if (r == hipSuccess) r = hipMalloc(&e.linkmask, (size_t)grid.x * 16 * sizeof(uint32_t));
+  if (r == hipSuccess) {
+    hipLaunchKernelGGL(k_face_table, grid, block, 0, nullptr, adj_dev, nbricks, e.faces);
+    hipLaunchKernelGGL(k_link_mask, grid, block, 0, nullptr, adj_dev, nbricks, e.linkmask);
+    r = hipGetLastError();
+  }
+  if (r == hipSuccess) r = hipStreamSynchronize(nullptr);
+  if (r != hipSuccess) {
+    free_entry(e);
+    HIP_TRY(r);
+  }
+  g_adj.push_back(e);
   return BRK_OK;
 }
 
@@ -602,9 +623,7 @@ extern "C" int brk_adjacency_release(const uint32_t *adj_dev) {
   std::lock_guard<std::mutex> lock(g_adj_mutex);
   for (size_t q = 0; q < g_adj.size(); ++q)
     if (g_adj[q].adj == adj_dev) {
-      for (auto &m : g_adj[q].masks) (void)hipFree(m.second); // hipFree waits for the kernels that still read it
-      if (g_adj[q].linkmask) (void)hipFree(g_adj[q].linkmask);
-      if (g_adj[q].faces) (void)hipFree(g_adj[q].faces);
+      free_entry(g_adj[q]);
       g_adj.erase(g_adj.begin() + q);
       return BRK_OK;
     }
@@ -697,8 +716,9 @@ extern "C" int brk_stencil_apply_box_ex(int id, const uint32_t *adj, const doubl
   cf.reverse = reverse ? 1u : 0u;
   if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) {
     const uint32_t *regmask = nullptr, *faces = nullptr; // registered adjacency: bricks whose face neighbours are the predicted ones skip their rows
-    if (int rc = regular_mask(adj, tot[0], tot[0] * tot[1], static_cast<hipStream_t>(s), &regmask)) return rc;
-    if (int rc = face_table(adj, static_cast<hipStream_t>(s), &faces)) return rc;
+    std::lock_guard<std::mutex> adj_lock(g_adj_mutex);   // until the launch is enqueued
+    if (int rc = regular_mask_locked(adj, tot[0], tot[0] * tot[1], static_cast<hipStream_t>(s), &regmask)) return rc;
+    if (int rc = face_table_locked(adj, &faces)) return rc;
     return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s), regmask, faces);
   }
   // other stencils: the same traversal order as an id list, built once per box geometry and kept on the device

@@ -452,8 +452,9 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
   // over a k-paired list 0.472 ms against 0.507 for k_star_wg on the tiled list (-6.8 %); over lists that are NOT paired it is no
   // faster (tiled list +0.3 %, BrickDecomp id ranges +3 %), and the 13-point stencil does not gain (0.395 either way: it is not
   // bound by its LDS footprint).  So: the radius-4 star over lists the caller declares k-paired (the box entry point builds its
-  // own); variant 3 forces it for experiments.
-  if ((stencil_id == BRK_MPI25 && kpaired) || variant == 3) {
+  // own) -- and the 13-point star when the caller declares its list k-paired (no gain, no loss: one declaration means the same for
+  // every stencil); variant 3 (development builds) forces it for experiments.
+  if (kpaired || variant == 3) {
     const uint32_t wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
     if (stencil_id == BRK_MPI13) hipLaunchKernelGGL((k_star_kp<kStarMpi13, 4>), dim3(wgs8), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
     else hipLaunchKernelGGL((k_star_kp<kStarMpi25, 3>), dim3(wgs8), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);

@@ -35,7 +35,8 @@ int main(int argc, char **argv) {
   populate_cart(bDecomp, cart, coo);
   BrickInfo<3> bInfo = bDecomp.getBrickInfo();
   BrickInfo<3> bInfo_dev = movBrickInfo(bInfo, hipMemcpyHostToDevice);
-  brkRegisterAdjacency(bInfo_dev); // written once: the library may keep compact tables next to it (brk_adjacency_register)
+  // written once: the library may keep compact tables next to it (brk_adjacency_register); released and freed when main leaves
+  brkAdjacencyScope<3> adjacency(bInfo_dev);
   const size_t bsize = 512;
   auto bStorage = bInfo.allocate(bsize), bOther = bInfo.allocate(bsize);
   const size_t total = (size_t)bStorage.chunks * bStorage.step;
@@ -120,6 +121,5 @@ int main(int argc, char **argv) {
   }
   free(bInfo.adj);
   std::cout << (ok ? "weak_hip: all exchanges match" : "weak_hip: FAILED") << std::endl;
-  fflush(stdout); // everything of ours is released: leave without the HIP / OpenMP runtimes' exit-time destructors (see strong_hip.cpp)
-  _Exit(ok ? 0 : 1);
+  return ok ? 0 : 1;
 }

@@ -77,7 +77,9 @@ int main(int argc, char **argv) {
 
     BrickInfo<3> bInfo = bDecomp.getBrickInfo();
     BrickInfo<3> bInfo_dev = movBrickInfo(bInfo, hipMemcpyHostToDevice);
-  brkRegisterAdjacency(bInfo_dev); // written once: the library may keep compact tables next to it (brk_adjacency_register)
+    // written once: the library may keep compact tables next to it (brk_adjacency_register); released, then freed, when this
+    // block is left -- also by an exception
+    brkAdjacencyScope<3> adjacency(bInfo_dev);
     const size_t bsize = 512;
     auto bStorage = bInfo.allocate(bsize), bStorageOut = bInfo.allocate(bsize);
     const size_t total = (size_t)bStorage.chunks * bStorage.step;

@@ -65,6 +65,21 @@ inline void brkReleaseAdjacency(const BrickInfo<dims> &bInfo_dev) {
   (void)brk_adjacency_release(reinterpret_cast<const uint32_t *>(bInfo_dev.adj));
 }
 
+// The pair above as a scope: registers in the constructor; the destructor releases and THEN frees the device table (the order the
+// contract asks for), so a driver cannot leave with the table registered or leaked -- also on an exception path.
+template <unsigned dims>
+struct brkAdjacencyScope {
+  BrickInfo<dims> &bInfo_dev;
+  explicit brkAdjacencyScope(BrickInfo<dims> &info_dev) : bInfo_dev(info_dev) { brkRegisterAdjacency(bInfo_dev); }
+  brkAdjacencyScope(const brkAdjacencyScope &) = delete;
+  brkAdjacencyScope &operator=(const brkAdjacencyScope &) = delete;
+  ~brkAdjacencyScope() {
+    brkReleaseAdjacency(bInfo_dev);
+    (void)gpuFree(bInfo_dev.adj);
+    bInfo_dev.adj = nullptr;
+  }
+};
+
 // OPTIONAL (not in the reference): direction of successive sweeps over the same bricks.  `brkSweepTurn t; ... brk_stencil_apply_box_ex(...,
 // t.flags(), stream)` inside the timed lambda walks the bricks forwards, backwards, forwards, ...: a sweep then starts in the part of
 // the field the Infinity Cache still holds from the one before (brk.h, BRK_SWEEP_REVERSE; results do not depend on it).

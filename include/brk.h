@@ -148,9 +148,9 @@ int brk_adjacency_release(const uint32_t *adj_dev);
 int brk_stencil_apply_taps(const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
                            const uint32_t *brick_ids_dev, uint32_t first, uint32_t n, uint32_t ntaps,
                            const int32_t *offsets_host, const double *weights_host, brk_stream s);
-/* Kernel variant selection for experiments/benchmarks: 0 = default.  A process-wide knob, NOT thread-safe with respect to
- * concurrent launches (a launch racing with a setter runs either variant; every variant computes the same result). */
-int brk_set_variant(int stencil_id, int variant);
+/* Development builds of the library (make -C bricklib_amd/csrc DEV=1 or VARIANTS=1) additionally export the experiment knobs
+ * used by tools/kbench (kernel variant selection, LDS padding, diagnostic modes), looked up with dlsym.  They are not declared
+ * here and the default libbrk.so does not contain them: not part of this ABI. */
 
 /* ---- region copies: pack / unpack / same-GPU halo links --------------------------------------------------------
  * Replaces RegionLink + cudaCopy (strong/main.cu:60-83, launched at :440-443,:459-462,:479-482) and the

@@ -17,6 +17,10 @@ pytestmark = pytest.mark.gpu
 def _set_variant_or_skip(lib, sid, variant):
     """the earlier kernel generations are compiled only with `make -C bricklib_amd/csrc VARIANTS=1` (tools/kbench A/B runs); the
     default build carries one kernel per stencil, and a variant test then has nothing to run"""
+    if not hasattr(lib, "brk_set_variant"):
+        if variant != 0:
+            pytest.skip("kernel variants are not part of this build (make -C bricklib_amd/csrc VARIANTS=1)")
+        return
     if variant != 0 and lib.brk_set_variant(sid, variant) != 0:
         pytest.skip("kernel variants are not part of this build (make -C bricklib_amd/csrc VARIANTS=1)")
     assert lib.brk_set_variant(sid, variant) == 0
@@ -309,7 +313,8 @@ def test_star7_kernel_variants(oracle, dev, name, variant):
             oracle.brick_stencil(NAMES[name], d.adj, hin2, want, 512, n=rng_[1] - rng_[0], first=rng_[0], coeff=coeff)
             assert np.abs(B.dat.cpu().numpy() - want).max() <= TOL, rng_
     finally:
-        lib.brk_set_variant(sid, 0)
+        if hasattr(lib, "brk_set_variant"):
+            lib.brk_set_variant(sid, 0)
 
 
 @pytest.mark.parametrize("size", [1, 2, 3, 8])
@@ -634,7 +639,8 @@ def test_cond_stencil(oracle, golden, dev, variant):
         oracle.brick_stencil(ST_COND7, bInfo.adj_host, hin, want, 512, ids=ids, coeff=coeff)
         assert np.abs(so.dat.cpu().numpy() - want).max() <= TOL
     finally:
-        lib.brk_set_variant(6, 0)
+        if hasattr(lib, "brk_set_variant"):
+            lib.brk_set_variant(6, 0)
 
 
 @pytest.mark.parametrize("name,variant", [("27pt", 0), ("27pt", 1), ("27pt", 2), ("27pt", 5), ("mpi125pt", 0), ("mpi125pt", 1),
@@ -683,7 +689,8 @@ def test_cube_kernel_variants(oracle, dev, name, variant):
             oracle.brick_stencil(NAMES[name], d.adj, hin2, want, 512, n=rng_[1] - rng_[0], first=rng_[0], coeff=coeff)
             assert np.abs(B.dat.cpu().numpy() - want).max() <= TOL, rng_
     finally:
-        lib.brk_set_variant(sid, 0)
+        if hasattr(lib, "brk_set_variant"):
+            lib.brk_set_variant(sid, 0)
 
 
 @pytest.mark.parametrize("nranks", [2, 8])
@@ -1306,8 +1313,8 @@ def test_registered_adjacency_box_form_is_bit_identical(oracle, dev):
 def test_star_two_bricks_per_wave_kpaired_lists(oracle, dev, shape):
     """k_star_kp (two bricks per wave; the planes between the two bricks of a k-pair are loaded once): the 25-point star over
     k-paired lists (brk_stencil_apply_list_kpaired; order.tiled(kpair=True)) with odd level counts, rows that are not multiples
-    of 4 and fewer rows than XCDs, and -- forced by variant 3, also for the 13-point star -- over lists that are NOT paired:
-    tiled, lexicographic, ragged, shuffled.  Always the oracle's result."""
+    of 4 and fewer rows than XCDs, and -- every list DECLARED k-paired, which selects the pair kernel for both stars whatever the
+    list really is -- over lists that are NOT paired: tiled, lexicographic, ragged, shuffled.  Always the oracle's result."""
     from bricklib_amd._lib import lib
     from bricklib_amd.order import tiled
     ni, nj, nk = shape
@@ -1327,13 +1334,9 @@ def test_star_two_bricks_per_wave_kpaired_lists(oracle, dev, shape):
             w = np.zeros_like(hin)
             oracle.brick_stencil(sid, info.adj_host, hin, w, 512, ids=np.ascontiguousarray(real))
             want[lname] = w
-        try:
-            for variant in (0, 3):
-                assert lib.brk_set_variant(sid, variant) == 0
-                for lname, ids in lists.items():
-                    out = bl.BrickStorage.allocate(info.nbricks, 512, dev)
-                    bl.apply_stencil(name, bl.Brick(info, st, 0), bl.Brick(info, out, 0), ids=grid_to_device(ids, dev), kpaired=lname.startswith("kpaired"))
-                    err = np.abs(out.dat.cpu().numpy() - want[lname]).max()
-                    assert err <= TOL, (name, variant, lname, err)
-        finally:
-            lib.brk_set_variant(sid, 0)
+        for declared in (False, True):
+            for lname, ids in lists.items():
+                out = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+                bl.apply_stencil(name, bl.Brick(info, st, 0), bl.Brick(info, out, 0), ids=grid_to_device(ids, dev), kpaired=declared or lname.startswith("kpaired"))
+                err = np.abs(out.dat.cpu().numpy() - want[lname]).max()
+                assert err <= TOL, (name, declared, lname, err)
