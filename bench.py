@@ -99,11 +99,13 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--windows", type=int, default=5, help="single workload: the K-step timed region is repeated this many times; the median is reported")
     ap.add_argument("--steady-seconds", type=float, default=2.0, help="single workload: extra steady-state figure over this many seconds of launches (0 = skip)")
-    ap.add_argument("--one-way", action="store_true",
-                    help="every sweep walks the bricks in the same direction. Default: successive sweeps over the same bricks alternate "
-                         "direction (BRK_SWEEP_REVERSE on every other launch: same bricks, same results), so a sweep starts in the part of "
-                         "the field the 256 MB Infinity Cache still holds from the one before; the single workload also reports the "
-                         "one-way kernel time beside it")
+    ap.add_argument("--alternate", action="store_true",
+                    help="headline with successive sweeps over the same bricks in ALTERNATING directions (BRK_SWEEP_REVERSE on every other "
+                         "launch: same bricks, same results): a sweep then starts in the part of the never-rewritten input the 256 MB "
+                         "Infinity Cache still holds from the one before, so part of the reads is not served by HBM.  Default (round 4): "
+                         "every sweep walks the bricks in the same direction -- value and roofline.frac are HBM numbers -- and the "
+                         "alternating figure is reported beside them (`alternating` block)")
+    ap.add_argument("--one-way", action="store_true", help="accepted for compatibility: one direction is the default")
     ap.add_argument("--weak-zigzag", action="store_true", help="weak workload: alternate the direction of successive sweeps too (no gain measured: "
                                                                 "a ping-pong sweep reads what the previous one wrote with non-temporal stores)")
     ap.add_argument("--no-config3", action="store_true", help="single workload: skip the 27-/125-/13-/25-point lines on the same grid")
@@ -154,11 +156,13 @@ def cpu_baseline(O, sid, info, st, step, ids, coeff, n_cells, seconds):
                       f"(OpenMP, {cores} threads), {dt:.1f} s"}
 
 
-def cpu_baseline_reference(n_cells_axis, seconds):
-    """The reference's OWN CPU code on this host: its `_TILEFOR` loop nest (stencils/stencils.h:30-38) around its `ST_CPU`
-    7-point arithmetic (stencils/fake.h:345-349) -- array layout, compiled in place into oracle/_ref/libbrickref.so
-    (oracle/ref_cpu_sweep.cpp) -- under the reference's `time_func`.  A stated baseline beside the port, never the target.
-    One call updates STRIDEG^3 = (N + 16)^3 points (the reference sweeps its ghost zone too); the rate counts those."""
+def cpu_baseline_reference(n_cells_axis, seconds, stencil="7pt", coeff=None):
+    """The reference's OWN CPU code on this host: its `_TILEFOR` loop nest (stencils/stencils.h:30-38) around the arithmetic of
+    the benchmarked stencil -- for the 7pt.py headline the seven-coefficient expression of d3pt7's arr_func
+    (stencils/3axis.cpp:31-37), for mpi7pt its `ST_CPU` macro (stencils/fake.h:345-349) -- array layout, compiled in place into
+    oracle/_ref/libbrickref.so (oracle/ref_cpu_sweep.cpp) with the reference's Release flags, under the reference's `time_func`.
+    A stated baseline, never the target.  One call updates STRIDEG^3 = (N + 16)^3 points (the reference sweeps its ghost zone
+    too); `value` counts only the N^3 useful points, `value_incl_ghost_zone` all of them."""
     import ctypes as C
     from bricklib_amd.timing import time_func
     path = os.path.join(ROOT, "oracle", "_ref", "libbrickref.so")
@@ -173,18 +177,25 @@ def cpu_baseline_reference(n_cells_axis, seconds):
     stride, points = int(L.ref_cpu_sweep_stride()), int(L.ref_cpu_sweep_points())
     a = np.random.default_rng(3).random(stride ** 3)
     b = np.zeros_like(a)
-    fn = L.ref_cpu_sweep_mpi7
-    fn.argtypes = [C.c_void_p, C.c_void_p]
     pa, pb = a.ctypes.data, b.ctypes.data
-    per_call, calls, dt = time_func(lambda: fn(pa, pb), seconds)
-    return {"value": points / per_call / 1e9, "unit": "GStencil/s", "cores": cores, "kind": "reference ST_CPU, array layout",
-            "useful_value": float(n_cells_axis) ** 3 / per_call / 1e9,
+    if stencil == "7pt" and hasattr(L, "ref_cpu_sweep_7pt"):
+        c7 = np.ascontiguousarray((coeff if coeff is not None else np.random.default_rng(1).random(7))[:7], dtype=np.float64)
+        L.ref_cpu_sweep_7pt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        pc = c7.ctypes.data
+        call, what = (lambda: L.ref_cpu_sweep_7pt(pa, pb, pc)), "the seven-coefficient expression of d3pt7's arr_func (stencils/3axis.cpp:31-37)"
+    else:
+        L.ref_cpu_sweep_mpi7.argtypes = [C.c_void_p, C.c_void_p]
+        call, what = (lambda: L.ref_cpu_sweep_mpi7(pa, pb)), "ST_CPU (stencils/fake.h:345-349: MPI_ALPHA / MPI_BETA)"
+    per_call, calls, dt = time_func(call, seconds)
+    return {"value": float(n_cells_axis) ** 3 / per_call / 1e9, "unit": "GStencil/s", "cores": cores,
+            "kind": "reference", "code": "reference _TILEFOR (stencils/stencils.h:30-38) + " + what + ", array layout, compiled in place (oracle/ref_cpu_sweep.cpp)",
+            "value_incl_ghost_zone": points / per_call / 1e9,
             "protocol": "time_func (stencils/stencils.h:40-53), TOT_TIME = %.0f s" % seconds,
-            "sample": f"{calls} calls of the reference's _TILEFOR + ST_CPU (7-point, MPI_ALPHA/MPI_BETA) over a {stride}^3 array: "
-                      f"{points} points per call incl. its ghost zone ({n_cells_axis}^3 useful = useful_value), OpenMP {cores} threads, {dt:.1f} s"}
+            "sample": f"{calls} calls over a {stride}^3 array: {points} points updated per call incl. the ghost zone it also sweeps, "
+                      f"{n_cells_axis}^3 of them useful (value counts only those), OpenMP {cores} threads, {dt:.1f} s"}
 
 
-def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, launches=100, nsample=512, warm_ms=150.0, zigzag=True):
+def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, launches=100, nsample=512, warm_ms=150.0, zigzag=False):
     """One of the other stencils of BASELINE configs 2-3 on the SAME 512^3 grid through the same box entry point, outside
     the timed headline: kernel time from HIP events on the launch stream, roofline fraction, sampled oracle check."""
     from bricklib_amd.stencils import STENCILS
@@ -193,8 +204,8 @@ def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, 
     bIn, bOut = bl.Brick(info, st, 0), bl.Brick(info, sto, off_out)
     zz = bl.Zigzag()
 
-    def sweep(one_way=False):
-        bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream, reverse=zigzag and not one_way and zz.turn())
+    def sweep(alternate=zigzag):
+        bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream, reverse=alternate and zz.turn())
 
     # the sampled oracle check of the previous stencil leaves the GPU idle for seconds: warm up until the clocks are back
     # (>= warm_ms of back-to-back launches) before the timed launches
@@ -211,14 +222,16 @@ def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, 
     for _ in range(launches):
         sweep()
     e1.record(stream)
-    for _ in range(launches if zigzag else 0):
-        sweep(one_way=True)
+    for _ in range(launches):
+        sweep(alternate=not zigzag)      # the other mode beside it
     e2.record(stream)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / launches
     cells = float(len(ids)) * 512.0
     ach = BYTES_PER_UPDATE * cells / (ms * 1e-3) / 1e9
-    r = {"kernel_ms": ms, "kernel_ms_one_way": e1.elapsed_time(e2) / launches if zigzag else ms, "GStencil/s": cells / (ms * 1e-3) / 1e9, "launches": launches,
+    other = e1.elapsed_time(e2) / launches
+    r = {"kernel_ms": ms, "kernel_ms_one_way": other if zigzag else ms, "kernel_ms_alternating": ms if zigzag else other,
+         "sweep_direction": "alternating" if zigzag else "one way", "GStencil/s": cells / (ms * 1e-3) / 1e9, "launches": launches,
          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                       "frac_of_measured_copy": ach / HBM_COPY_GBS}}
     if O is not None:
@@ -321,10 +334,10 @@ def run_single(args, bl, dev):
     box = (0, (SB, SB, SB), (1, 1, 1), (NB, NB, NB))     # the reference launch: dim3 block(NB,NB,NB), b = grid[GB+z][GB+y][GB+x]
 
     zz = bl.Zigzag()
-    zigzag = not args.one_way
+    zigzag = bool(args.alternate) and not args.one_way
 
-    def step(one_way=False):
-        rev = zigzag and not one_way and zz.turn()
+    def step(one_way=False, alternate=False):
+        rev = (alternate or (zigzag and not one_way)) and zz.turn()
         if args.form == "box":
             bl.apply_stencil(sid, bIn, bOut, box=box, coeff=coeff, stream=stream, reverse=rev)
         else:
@@ -388,20 +401,25 @@ def run_single(args, bl, dev):
         wins.append((time.perf_counter() - t0, e0.elapsed_time(e1) / K))
     order = sorted(range(len(wins)), key=lambda q: wins[q][0])
     wall, kern_ms = wins[order[len(order) // 2]]
-    if zigzag:      # the same launches, all in one direction, beside the headline (not part of it)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(W):
-            step(one_way=True)
-        e0.record(stream)
-        for _ in range(max(K, 50)):
-            step(one_way=True)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        one_ms = e0.elapsed_time(e1) / max(K, 50)
-        extra["one_way"] = {"kernel_ms": one_ms, "value": cells / (one_ms * 1e-3) / 1e9, "unit": "GStencil/s",
-                            "roofline_frac": BYTES_PER_UPDATE * cells / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "what": "every launch walks the bricks in the same direction (--one-way); the headline alternates the direction of "
-                                    "successive sweeps (BRK_SWEEP_REVERSE), which lets a sweep start in what the Infinity Cache still holds"}
+    # the same launches in the other mode, beside the headline (not part of it): alternating directions when the headline is one
+    # way (the default), one way when it alternates
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    side = (lambda: step(one_way=True)) if zigzag else (lambda: step(alternate=True))
+    for _ in range(W):
+        side()
+    e0.record(stream)
+    for _ in range(max(K, 50)):
+        side()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    side_ms = e0.elapsed_time(e1) / max(K, 50)
+    extra["one_way" if zigzag else "alternating"] = {
+        "kernel_ms": side_ms, "value": cells / (side_ms * 1e-3) / 1e9, "unit": "GStencil/s",
+        "roofline_frac": BYTES_PER_UPDATE * cells / (side_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "what": ("every launch walks the bricks in the same direction; the headline of this run alternates (--alternate)" if zigzag else
+                 "successive sweeps in alternating directions (--alternate makes this the headline): a sweep starts in the part of the never-rewritten "
+                 "input the Infinity Cache still holds, so this fraction is algorithmic bytes / time / 8 TB/s with part of the reads NOT served by HBM; "
+                 "the headline (one direction) is the HBM number")}
     res = {"workload": f"single-{name}-{N}" + (f"-variant{args.variant}" if args.variant else ""), "layout": args.layout, "form": args.form, "sweep_direction": "alternating" if zigzag else "one way", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
            "kernel": "%s over %d bricks" % ("k_s7_wg<8 waves>" if name in ("7pt", "mpi7pt") else ("k_star_wg" if name in ("mpi13pt", "mpi25pt") else "k_cube_dense"), ids.size)}
@@ -424,22 +442,33 @@ def run_single(args, bl, dev):
         try:      # HBM-side traffic per launch of these kernels from the committed PMC passes (static, like roofline.traffic)
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_by_stencil.json")))
             for nm in blk:
-                if N == 512 and nm in pt["traffic_bytes_per_launch"]:
+                if N == 512 and nm in pt["traffic_bytes_per_launch"] and pt.get("sweep_direction") == blk[nm]["sweep_direction"]:
                     blk[nm]["roofline"]["traffic"] = pt["traffic_bytes_per_launch"][nm]
                     blk[nm]["roofline"]["traffic_source"] = "profiles/pmc_traffic_by_stencil.json"
         except Exception:
             pass
         extra["config3"] = {"workload": "single-{27pt,mpi125pt}-%d (+ 13/25-point), same box entry point" % N, **blk}
-    if O is not None and not args.no_cpu_baseline:
-        try:
-            extra["cpu_baseline"] = cpu_baseline(O, sid, info, st, step_e, ids, coeff, cells, args.cpu_seconds)
-        except Exception as e:
-            extra["oracle_error"] = repr(e)
     if not args.no_cpu_baseline:
-        try:        # second, clearly labelled leg: the reference's own array code (only built for 512^3)
-            extra["cpu_baseline_reference"] = cpu_baseline_reference(N, min(args.cpu_seconds, 8.0))
+        # cpu_baseline = the reference's own CPU code (kind "reference"; built for 512^3 7-point sweeps where /root/reference was
+        # present); cpu_baseline_port = the brick-layout restatement (kind "port") beside it.  Where the reference leg is not
+        # available (another size or stencil) the port is the baseline of the line.
+        ref_leg = None
+        try:
+            if name in ("7pt", "mpi7pt"):
+                ref_leg = cpu_baseline_reference(N, args.cpu_seconds, name, coeff)
         except Exception as e:
-            extra["cpu_baseline_reference"] = {"error": repr(e)}
+            extra["cpu_baseline_reference_error"] = repr(e)
+        port_leg = None
+        if O is not None:
+            try:
+                port_leg = cpu_baseline(O, sid, info, st, step_e, ids, coeff, cells, min(args.cpu_seconds, 8.0) if ref_leg else args.cpu_seconds)
+            except Exception as e:
+                extra["oracle_error"] = repr(e)
+        if ref_leg is not None:
+            extra["cpu_baseline"] = ref_leg
+            extra["cpu_baseline_port"] = port_leg
+        else:
+            extra["cpu_baseline"] = port_leg
     return res, extra
 
 
@@ -723,7 +752,7 @@ def run_strong(args, bl, dev, rank, world):
 
     def step():
         sr.exchange(transport, main)
-        sr.sweeps(sid, stream=main, zigzag=not args.one_way)
+        sr.sweeps(sid, stream=main, zigzag=bool(args.alternate))
 
     for _ in range(W):
         step()
@@ -895,9 +924,11 @@ def main():
         # stored measurement is for another workload
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt.get("workload") == res["workload"]:
-                out["roofline"]["traffic"] = pt["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json"
+            # the stored measurement must be for THIS run's workload, entry form and sweep direction; otherwise null
+            key = "%s/%s/%s" % (res["workload"], res.get("form", "-"), res.get("sweep_direction", "-"))
+            if key in pt.get("runs", {}):
+                out["roofline"]["traffic"] = pt["runs"][key]["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/pmc_traffic.json [%s]: %s" % (key, pt["runs"][key].get("source", ""))
         except Exception:
             pass
         out.update(extra)

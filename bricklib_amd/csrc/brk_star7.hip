@@ -368,6 +368,127 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
 #endif
 }
 
+
+// ---- two bricks per wave ------------------------------------------------------------------------------------------------------
+// A workgroup of NW waves takes 2 NW list entries -- a run A of NW entries and the run B behind it -- and wave w handles entry w of
+// both: everything the two bricks need is requested up front (twice the bytes in flight per wave), both are staged in their own
+// tiles, ONE barrier, then both are computed.  When B is a face neighbour of A the face between them is never requested:
+//   B = A's +k neighbour (k-paired lists)   A's upper k-plane IS B.own[0], B's lower k-plane IS A.own[7]: registers of the same lane;
+//   B = A's +j neighbour (j-paired lists)   A's +j halo row IS row 0 of B's tile, B's -j halo row IS row 7 of A's tile: the lanes on
+//                                           that edge point their ds_read at the partner's tile (a tile is 768 doubles = a multiple
+//                                           of the 64 banks, and halo row 9 shares its banks with row 1: still conflict-free).
+// A j-face costs 8 half-used 128-byte lines, a k-face 4 full ones; per brick the requests through the vector L1 go from 56 to 52
+// (k-pairs) or 48 (j-pairs).  Any list is computed correctly: unpaired entries load all their faces, entries without an i-sibling in
+// their run gather their columns into the fallback slots, padding entries idle.
+template <int KIND, int NW, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void k_s7_2t(const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                                        double *__restrict__ out, size_t step, const uint32_t *__restrict__ ids,
+                                                        uint32_t first, uint32_t n, Coeffs cf, const uint32_t *__restrict__ faces) {
+  __shared__ double lds[2 * NW * kTile];
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + wg_in_xcd(cf, per_xcd);
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 3, lo = lane & 7;
+  double *tileA = lds + w * kTile, *tileB = lds + (NW + w) * kTile; // the A tiles side by side (siblings at -+kTile), then the B tiles
+  constexpr int kAB = NW * kTile;                                   // tileB - tileA
+  auto entry = [&](uint32_t sl) -> uint32_t { return sl < n ? __builtin_amdgcn_readfirstlane(ids ? ids[sl] : first + sl) : BRK_LIST_SKIP; };
+  const uint32_t slotA = wg * 2 * NW + w, slotB = slotA + NW;
+  const uint32_t bA = entry(slotA), bB = entry(slotB);
+  const bool actA = bA != BRK_LIST_SKIP, actB = bB != BRK_LIST_SKIP;
+  double ownA[8], ownB[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ownA[k] = ownB[k] = 0.0;
+  if (actA) {
+    const gcptr self = sbase(in + (size_t)bA * step);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ownA[k] = self[k * 64 + lane];
+  }
+  if (actB) {
+    const gcptr self = sbase(in + (size_t)bB * step);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ownB[k] = self[k * 64 + lane];
+  }
+  __builtin_amdgcn_sched_barrier(0); // own planes are in flight before anything waits for an adjacency row
+  Nbr nA{}, nB{};
+  if (actA) nA = load_nbr(adj, faces, bA);
+  if (actB) nB = load_nbr(adj, faces, bB);
+  const uint32_t pA = w > 0 ? entry(slotA - 1) : BRK_LIST_SKIP, qA = w + 1 < NW ? entry(slotA + 1) : BRK_LIST_SKIP;
+  const uint32_t pB = w > 0 ? entry(slotB - 1) : BRK_LIST_SKIP, qB = w + 1 < NW ? entry(slotB + 1) : BRK_LIST_SKIP;
+  auto u = [](uint32_t x) { return __builtin_amdgcn_readfirstlane(x); };
+  const bool shA_im = actA && pA != BRK_LIST_SKIP && u(nA.im) == pA, shA_ip = actA && qA != BRK_LIST_SKIP && u(nA.ip) == qA;
+  const bool shB_im = actB && pB != BRK_LIST_SKIP && u(nB.im) == pB, shB_ip = actB && qB != BRK_LIST_SKIP && u(nB.ip) == qB;
+  const bool kpaired = actA && actB && u(nA.kp) == bB && u(nB.km) == bA;
+  const bool jpaired = actA && actB && u(nA.jp) == bB && u(nB.jm) == bA;
+  double kmA = 0.0, kpA = 0.0, kmB = 0.0, kpB = 0.0, jmA = 0.0, jpA = 0.0, jmB = 0.0, jpB = 0.0, imA = 0.0, ipA = 0.0, imB = 0.0, ipB = 0.0;
+  if (actA) {
+    kmA = sbase(in + (size_t)u(nA.km) * step)[7 * 64 + lane];
+    jmA = sbase(in + (size_t)u(nA.jm) * step)[hi * 64 + 7 * 8 + lo];
+    if (!kpaired) kpA = sbase(in + (size_t)u(nA.kp) * step)[lane];
+    if (!jpaired) jpA = sbase(in + (size_t)u(nA.jp) * step)[hi * 64 + lo];
+    if (!shA_im) imA = sbase(in + (size_t)u(nA.im) * step)[hi * 64 + lo * 8 + 7];
+    if (!shA_ip) ipA = sbase(in + (size_t)u(nA.ip) * step)[hi * 64 + lo * 8];
+  }
+  if (actB) {
+    kpB = sbase(in + (size_t)u(nB.kp) * step)[lane];
+    jpB = sbase(in + (size_t)u(nB.jp) * step)[hi * 64 + lo];
+    if (!kpaired) kmB = sbase(in + (size_t)u(nB.km) * step)[7 * 64 + lane];
+    if (!jpaired) jmB = sbase(in + (size_t)u(nB.jm) * step)[hi * 64 + 7 * 8 + lo];
+    if (!shB_im) imB = sbase(in + (size_t)u(nB.im) * step)[hi * 64 + lo * 8 + 7];
+    if (!shB_ip) ipB = sbase(in + (size_t)u(nB.ip) * step)[hi * 64 + lo * 8];
+  }
+  // ---- stage both bricks
+  if (actA) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tileA[k * kPlane + (hi + 1) * 8 + lo] = ownA[k];
+    tileA[hi * kPlane + lo] = jmA;
+    if (!jpaired) tileA[hi * kPlane + 72 + lo] = jpA;
+    if (!shA_im) tileA[hi * kPlane + 80 + lo] = imA;
+    if (!shA_ip) tileA[hi * kPlane + 88 + lo] = ipA;
+  }
+  if (actB) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tileB[k * kPlane + (hi + 1) * 8 + lo] = ownB[k];
+    tileB[hi * kPlane + 72 + lo] = jpB;
+    if (!jpaired) tileB[hi * kPlane + lo] = jmB;
+    if (!shB_im) tileB[hi * kPlane + 80 + lo] = imB;
+    if (!shB_ip) tileB[hi * kPlane + 88 + lo] = ipB;
+  }
+  __syncthreads(); // every tile of the group is complete
+  if (actA) {
+    gptr dst = (gptr)(out + (size_t)bA * step);
+    asm volatile("" : "+s"(dst));
+    const int o_jm = hi * 8 + lo;
+    const int o_jp = (hi < 7 || !jpaired) ? (hi + 2) * 8 + lo : kAB + 8 + lo; // row 0 of the partner's brick = its tile row 1
+    const int o_im = lo > 0 ? (hi + 1) * 8 + lo - 1 : (shA_im ? -kTile + (hi + 1) * 8 + 7 : 80 + hi);
+    const int o_ip = lo < 7 ? (hi + 1) * 8 + lo + 1 : (shA_ip ? kTile + (hi + 1) * 8 : 88 + hi);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double jm = tileA[k * kPlane + o_jm], jp = tileA[k * kPlane + o_jp];
+      const double im = tileA[k * kPlane + o_im], ip = tileA[k * kPlane + o_ip];
+      const double km = k == 0 ? kmA : ownA[k > 0 ? k - 1 : 0];
+      const double kp = k == 7 ? (kpaired ? ownB[0] : kpA) : ownA[k < 7 ? k + 1 : 7];
+      store_result(&dst[k * 64 + lane], point7<KIND>(kp, km, jp, jm, ip, im, ownA[k], cf));
+    }
+  }
+  if (actB) {
+    gptr dst = (gptr)(out + (size_t)bB * step);
+    asm volatile("" : "+s"(dst));
+    const int o_jm = (hi > 0 || !jpaired) ? hi * 8 + lo : -kAB + 8 * 8 + lo; // row 7 of the partner's brick = its tile row 8
+    const int o_jp = (hi + 2) * 8 + lo;
+    const int o_im = lo > 0 ? (hi + 1) * 8 + lo - 1 : (shB_im ? -kTile + (hi + 1) * 8 + 7 : 80 + hi);
+    const int o_ip = lo < 7 ? (hi + 1) * 8 + lo + 1 : (shB_ip ? kTile + (hi + 1) * 8 : 88 + hi);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double jm = tileB[k * kPlane + o_jm], jp = tileB[k * kPlane + o_jp];
+      const double im = tileB[k * kPlane + o_im], ip = tileB[k * kPlane + o_ip];
+      const double km = k == 0 ? (kpaired ? ownA[7] : kmB) : ownB[k > 0 ? k - 1 : 0];
+      const double kp = k == 7 ? kpB : ownB[k < 7 ? k + 1 : 7];
+      store_result(&dst[k * 64 + lane], point7<KIND>(kp, km, jp, jm, ip, im, ownB[k], cf));
+    }
+  }
+}
+
 } // namespace
 
 int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step,
@@ -389,7 +510,18 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
     else BRK_LAUNCH_WG_K(kCoeff, W);              \
   } while (0)
 #ifdef BRK_VARIANTS
-  if (variant == 6) {
+  if (variant == 7 || variant == 8 || variant == 9) { // two bricks per wave (two tiles): 7 = 4-wave groups at 3 per CU, 8 = 4-wave groups at 2 per CU, 9 = 8-wave groups
+#define BRK_LAUNCH_2T(K)                                                                                                                              \
+  do {                                                                                                                                                \
+    if (variant == 7) hipLaunchKernelGGL((k_s7_2t<K, 4, 3>), dim3((((n + 7) / 8 + 7) / 8) * 8), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces); \
+    else if (variant == 8) hipLaunchKernelGGL((k_s7_2t<K, 4, 2>), dim3((((n + 7) / 8 + 7) / 8) * 8), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces); \
+    else hipLaunchKernelGGL((k_s7_2t<K, 8, 1>), dim3((((n + 15) / 16 + 7) / 8) * 8), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces); \
+  } while (0)
+    if (kind == kMpi) BRK_LAUNCH_2T(kMpi);
+    else if (kind == kCond) BRK_LAUNCH_2T(kCond);
+    else BRK_LAUNCH_2T(kCoeff);
+#undef BRK_LAUNCH_2T
+  } else if (variant == 6) {
     const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
     BRK_LAUNCH_WG_W(4);
   } else if (variant == 2) {

@@ -26,3 +26,14 @@ extern "C" void ref_cpu_sweep_mpi7(const bElem *in_ptr, bElem *out_ptr) {
   auto arrOut = (bElem(*)[STRIDE][STRIDE])out_ptr;
   _TILEFOR ST_CPU;
 }
+
+// the same loop nest around the arithmetic of d3pt7's arr_func itself (stencils/3axis.cpp:31-37: seven coefficients, its term
+// order) -- the stencil of the GPU headline (7pt.py).  The expression sits inside a lambda of d3pt7() there (that function also
+// needs generated code, so it cannot be compiled from where it lies); it is restated here under the reference's own `_TILEFOR`.
+extern "C" void ref_cpu_sweep_7pt(const bElem *in_ptr, bElem *out_ptr, const bElem *coeff) {
+  auto arr_in = (bElem(*)[STRIDE][STRIDE])in_ptr;
+  auto arr_out = (bElem(*)[STRIDE][STRIDE])out_ptr;
+  _TILEFOR arr_out[k][j][i] = coeff[5] * arr_in[k + 1][j][i] + coeff[6] * arr_in[k - 1][j][i] + coeff[3] * arr_in[k][j + 1][i] +
+                              coeff[4] * arr_in[k][j - 1][i] + coeff[1] * arr_in[k][j][i + 1] + coeff[2] * arr_in[k][j][i - 1] +
+                              coeff[0] * arr_in[k][j][i];
+}

@@ -51,7 +51,7 @@ d = json.loads([l for l in open(sys.argv[1] + '/bench_default.json') if l.starts
 print('headline', round(d['value'], 1), 'frac', round(d['roofline']['frac'], 4), 'steady', round(d['steady_state']['value'], 1))
 for k, v in d['config3'].items():
     if isinstance(v, dict): print(' ', k, round(v['kernel_ms'], 4), 'ms frac', round(v['roofline']['frac'], 3), 'err', v.get('max_abs_err_vs_oracle'))
-print('cpu port', d['cpu_baseline']['value'], d['cpu_baseline']['cores'], '| cpu reference', (d.get('cpu_baseline_reference') or {}).get('value'))
+print('cpu', d['cpu_baseline']['kind'], d['cpu_baseline']['value'], d['cpu_baseline']['cores'], '| port', (d.get('cpu_baseline_port') or {}).get('value'), '| alternating', (d.get('alternating') or {}).get('kernel_ms'))
 PY
   checks prof > $d/prof.log 2>&1; tail -12 $d/prof.log
   cp $(ls -t $(find gpurun_out/prof_kt -name "*kernel_stats.csv") | head -1) $d/kernel_stats.csv
@@ -197,11 +197,20 @@ for k in ("single", "weak", "strong"):
     print(w or "alternating", k, round(d["value"], 1), d["unit"], "ms/step", round(d["ms_per_step"], 4), "frac", round(d["roofline"]["frac"], 4), extra)
 PY
   done ;;
+pair7)   # 7-point: two bricks per wave (variants 7 / 8 / 9, dev build) over k-paired and j-paired lists against the default kernel (list form, registered)
+  run -n 512 -s 0 -S -o 8 -v 100 -i 60 -r2 3
+  for ax in -P -J; do
+    run -n 512 -s 0 -S -o 8 $ax -G 4 -v 107,108,100 -i 60 -r2 3
+    run -n 512 -s 0 -S -o 8 $ax -G 8 -v 109,100 -i 60 -r2 3
+  done
+  run -n 512 -s 0 -S -o 4 -J -G 4 -v 107 -i 60 -r2 2
+  run -n 512 -s 0 -S -o 2 -J -G 4 -v 107 -i 60 -r2 2
+  run -n 512 -s 0 -S -b -v 100 -i 60 -r2 3 ;;
 reg7)    # 7-point box kernel with / without brk_adjacency_register
   for r in 1 2 3; do run -n 512 -s 0 -S -b -v 0 -i 60; run -n 512 -s 0 -S -b -v 0 -i 60 -R; done ;;
 order7)  # 7-point list form: rows per block of the XCD slab order
   for o in 2 4 8 16; do run -n 512 -s 0 -S -o $o -v 0 -i 60; done ;;
 
 *) echo "unknown recipe $recipe"; exit 2 ;;
-esac; } 2>&1 | tee gpurun_out/r03_$recipe.txt ;;
+esac; } 2>&1 | tee gpurun_out/r04_$recipe.txt ;;
 esac
