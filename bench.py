@@ -472,6 +472,107 @@ def run_single(args, bl, dev):
     return res, extra
 
 
+def rccl_library(comm):
+    """which RCCL the C-ABI transport is bound to (brk_comm_library: an RCCL the process has already mapped -- torch's -- is
+    preferred over loading a second instance); None when the run has no C-ABI communicator"""
+    if comm is None:
+        return None
+    from bricklib_amd.decomp import Comm
+    try:
+        return Comm.library()
+    except Exception as e:
+        return repr(e)
+
+
+def _phase_stats(rows, cycle_ms, world):
+    """rows: per probed cycle a dict of phase -> ms on this rank; returns phase -> {min, avg, max, sigma} over ranks of the
+    per-rank mean, the reference's statistics lines on stderr (rank 0), and the part of the exchange the timed cycles did not hide"""
+    from bricklib_amd.timing import format_stats, rank_statistics
+    keys = list(rows[0].keys())
+    mine = {k: sum(r[k] for r in rows) / len(rows) for k in keys}
+    out = {k: rank_statistics(mine[k], world) for k in keys}
+    out["cycle_ms_timed"] = cycle_ms
+    out["exposed_exchange_ms"] = max(0.0, cycle_ms - out["calc_ms"]["max"])
+    out["what"] = ("per-cycle phase times measured AFTER the timed region, in order on one stream, HIP events (host_call_ms: host time "
+                   "inside the transport call); {min, avg, max, sigma} over ranks of each rank's mean over %d cycles, the reference's "
+                   "mpi_statistics (include/brick-mpi.h:758-793); exposed_exchange_ms = timed cycle - max calc" % len(rows))
+    if int(os.environ.get("RANK", "0")) == 0 and (world > 1 or "WORLD_SIZE" not in os.environ or os.environ.get("WORLD_SIZE") == "1"):
+        for k in keys:
+            sys.stderr.write("bench.py: " + format_stats(k[:-3], out[k]) + "\n")
+    return out
+
+
+def phase_probe_weak(ex, calc, main, world, cycle_ms, cycles=5):
+    import torch.distributed as dist
+    from bricklib_amd.timing import marker
+    rows = []
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for it in range(cycles + 1):
+        marks, host_call = [], 0.0
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        for st in range(ex.nstages):
+            e = [ev() for _ in range(4)]
+            e[0].record(main)
+            with marker("pack"):
+                ex.exchange_begin(main, st)
+            e[1].record(main)
+            t0 = time.perf_counter()
+            with marker("transport"):
+                ex.exchange_transport(main, st)
+            host_call += time.perf_counter() - t0
+            e[2].record(main)
+            with marker("unpack"):
+                ex.exchange_end(main, st)
+            e[3].record(main)
+            marks.append(e)
+        c0, c1 = ev(), ev()
+        c0.record(main)
+        with marker("calc"):
+            calc()
+        c1.record(main)
+        torch.cuda.synchronize()
+        if it == 0:
+            continue        # first probed cycle: warm-up
+        rows.append({"pack_ms": sum(e[0].elapsed_time(e[1]) for e in marks), "transport_ms": sum(e[1].elapsed_time(e[2]) for e in marks),
+                     "unpack_ms": sum(e[2].elapsed_time(e[3]) for e in marks), "calc_ms": c0.elapsed_time(c1), "host_call_ms": host_call * 1e3})
+    return _phase_stats(rows, cycle_ms, world)
+
+
+def phase_probe_strong(sr, transport, calc, main, world, cycle_ms, cycles=3):
+    import torch.distributed as dist
+    from bricklib_amd.timing import marker
+    rows = []
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for it in range(cycles + 1):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e = [ev() for _ in range(5)]
+        e[0].record(main)
+        with marker("pack"):
+            sr.exchange_begin(main)
+        e[1].record(main)
+        t0 = time.perf_counter()
+        with marker("transport"):
+            if sr.peers:
+                transport(sr, main)
+        host_call = time.perf_counter() - t0
+        e[2].record(main)
+        with marker("unpack"):
+            sr.exchange_end(main)
+        e[3].record(main)
+        with marker("calc"):
+            calc()
+        e[4].record(main)
+        torch.cuda.synchronize()
+        if it:
+            rows.append({"pack_ms": e[0].elapsed_time(e[1]), "transport_ms": e[1].elapsed_time(e[2]), "unpack_ms": e[2].elapsed_time(e[3]),
+                         "calc_ms": e[3].elapsed_time(e[4]), "host_call_ms": host_call * 1e3})
+    return _phase_stats(rows, cycle_ms, world)
+
+
 def run_weak(args, bl, dev, rank, world):
     import torch.distributed as dist
     from bricklib_amd.decomp import Exchanger, rank_to_coo
@@ -658,7 +759,15 @@ def run_weak(args, bl, dev, rank, world):
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
-    # outside the timed region: the exchange alone (device links + RCCL), for reading the scaling numbers
+    # outside the timed region: where a cycle's time goes, phase by phase, in order on one stream -- the reference's pack / call /
+    # wait / calc lines (weak/main.cpp:271-289) for a GPU-resident exchange: pack (links + packing launch), transport (the
+    # ncclSend/ncclRecv group: host call time and device time), unpack, calc (the S passes with no exchange); min / avg / max /
+    # sigma over ranks as mpi_statistics does.  The timed cycles above may overlap these phases (schedule); what they could
+    # not hide is `exposed_exchange_ms` = timed cycle - calc.
+    probe_lists = lists if isinstance(lists, SweepLists) else whole
+    phases = phase_probe_weak(ex, lambda: weak_cycle(sid, d, A, B, lambda s_: None, main=main, comm=None, overlap=False, lists=probe_lists),
+                              main, world, wall / K * 1e3)
+    # ... and the exchange alone (device links + RCCL), for reading the scaling numbers
     xs, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     xs.record(main)
     for _ in range(5):
@@ -683,7 +792,7 @@ def run_weak(args, bl, dev, rank, world):
            "kernel": "%s passes over brick lists of BrickDecomp(%d^3): %d passes (%d sweeps) + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S * upd, S),
            "cart": cart, "overlap": overlap, "exchange": args.exchange, "transport": transport, "transport_fallback_reason": fallback_reason, "exchange_self_check": self_check,
            "schedule": schedule, "deep_depth": deep_depth if schedule == "deep" else None, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
-           "remote_bytes_per_rank": ex.bytes_remote, "messages_per_exchange": ex.messages,
+           "remote_bytes_per_rank": ex.bytes_remote, "messages_per_exchange": ex.messages, "phases": phases, "rccl_library": rccl_library(comm),
            "per_peer_send_bytes": {str(k): v for k, v in sorted(per_peer.items())},
            "per_peer_GBps_exchange_alone": {str(k): v / (exchange_ms * 1e-3) / 1e9 for k, v in sorted(per_peer.items())} if exchange_ms > 0 else None}
     extra = {}
@@ -775,6 +884,7 @@ def run_strong(args, bl, dev, rank, world):
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+    phases = phase_probe_strong(sr, transport, lambda: sr.sweeps(sid, stream=main, zigzag=bool(args.alternate)), main, world, wall / K * 1e3)
     sum1 = global_sum()
     drift = abs(sum1 - sum0) / abs(sum0) if name in ("mpi7pt", "mpi13pt", "mpi25pt", "mpi125pt", "mpi7pt_x2") else None
     upd = 2 if name.endswith("_x2") else 1
@@ -788,7 +898,7 @@ def run_strong(args, bl, dev, rank, world):
            # ghost runs between two subdomains of one rank: reached through the adjacency table ("aliased": neither copied nor swept)
            # or copied by device links as in the reference ("copied"); bricks per sweep over subdomains + ghost rings vs subdomain bricks
            "local_ghosts": args.strong_local_ghosts, "local_link_bytes_per_rank": sr.bytes_local,
-           "swept_bricks_per_sweep": sr.swept_bricks, "subdomain_bricks": sr.nsub * (args.strong_sub // 8) ** 3,
+           "swept_bricks_per_sweep": sr.swept_bricks, "subdomain_bricks": sr.nsub * (args.strong_sub // 8) ** 3, "phases": phases, "rccl_library": rccl_library(comm),
            "transport": ("abi" if comm is not None else ("gloo-staged" if args.backend == "gloo" else "torch")) if world > 1 else "device links"}
     if comm is not None:
         torch.cuda.synchronize()
@@ -913,7 +1023,7 @@ def main():
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
                        **{k: res[k] for k in ("layout", "form", "sweep_direction", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift", "transport", "transport_fallback_reason", "exchange_self_check", "messages_per_exchange",
-                                             "per_peer_send_bytes", "per_peer_GBps_exchange_alone", "distinct_gpus", "ranks_seen",
+                                             "per_peer_send_bytes", "per_peer_GBps_exchange_alone", "distinct_gpus", "ranks_seen", "phases", "rccl_library",
                                              "local_ghosts", "local_link_bytes_per_rank", "swept_bricks_per_sweep", "subdomain_bricks") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_by_step": ach_step / HBM_PEAK_GBS,

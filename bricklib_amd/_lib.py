@@ -128,6 +128,8 @@ def _load():
     L.brk_comm_rank.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.brk_decomp_build_order.argtypes = [C.c_uint32 * 3, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(vp)]
     L.brk_skin3d_order.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.brk_comm_library.restype = C.c_char_p
+    L.brk_comm_library.argtypes = []
     L.brk_adjacency_register.argtypes = [vp, C.c_uint32]
     L.brk_adjacency_release.argtypes = [vp]
     return L
@@ -148,7 +150,7 @@ ABI_SYMBOLS = [
     "brk_xplan_ncopies", "brk_xplan_copies", "brk_xplan_nmsgs", "brk_xplan_msgs", "brk_xplan_bytes_remote",
     "brk_xplan_bytes_local", "brk_xplan_buffer_bytes", "brk_exchange_view_create", "brk_exchange_view_free",
     "brk_exchange_begin", "brk_exchange_transport", "brk_exchange_end", "brk_exchange_run", "brk_exchange_loopback",
-    "brk_exchange_view_buffer", "brk_exchange", "brk_comm_unique_id", "brk_comm_init_rank", "brk_comm_destroy", "brk_comm_rank",
+    "brk_exchange_view_buffer", "brk_exchange", "brk_comm_unique_id", "brk_comm_init_rank", "brk_comm_destroy", "brk_comm_rank", "brk_comm_library",
     "brk_adjacency_register", "brk_adjacency_release", "brk_decomp_build_order", "brk_skin3d_order",
 ]
 

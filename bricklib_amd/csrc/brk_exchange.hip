@@ -4,8 +4,10 @@
 //   end        one brk_link_copy launch: unpacking
 // This is the GPU-resident replacement of BrickDecomp::exchange / ExchangeView::exchange / MultiStageExchangeView::exchange
 // (reference include/brick-mpi.h:82-165,466-495) and of the strong driver's pack -> MPI -> unpack (strong/main.cu:367-482).
-// librccl is loaded on first use (dlopen): single-GPU users and CPU-only hosts never need it; inside a PyTorch process the
-// already loaded RCCL (same soname) is the one that answers.
+// librccl is bound on first use: single-GPU users and CPU-only hosts never need it.  ONE RCCL per process: an RCCL that is
+// already mapped (PyTorch ships its own librccl.so under torch/lib and maps it at import) is the one this library binds to --
+// dlopen(RTLD_NOLOAD) over the candidate names, then dlsym(RTLD_DEFAULT) -- and only when there is none is librccl.so.1 loaded.
+// brk_comm_library() says which file answered (dladdr).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #if __has_include(<rccl/rccl.h>)
@@ -52,6 +54,7 @@ struct Rccl {
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   char why[256] = "";
+  char path[512] = ""; // the file ncclCommInitRank was bound from
 };
 
 Rccl &rccl_state() {
@@ -63,10 +66,20 @@ Rccl *rccl() {
   Rccl &R = rccl_state();
   static std::once_flag once;
   std::call_once(once, [&R] {
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      R.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // (1) an RCCL instance this process has mapped already: same communicator pool, one set of proxy threads, one IPC registry
+    static const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *name : names) {
+      R.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
       if (R.handle) break;
     }
+    if (!R.handle && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) {
+      // mapped under another name or path (torch/lib/librccl.so loaded by path): the global scope answers; find its file and
+      // take a handle of exactly that object so that every symbol below comes from the same library
+      Dl_info info;
+      if (dladdr(dlsym(RTLD_DEFAULT, "ncclCommInitRank"), &info) && info.dli_fname) R.handle = dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD);
+    }
+    // (2) none mapped: load one
+    for (size_t q = 0; !R.handle && q < sizeof names / sizeof *names; ++q) R.handle = dlopen(names[q], RTLD_NOW | RTLD_GLOBAL);
     if (!R.handle) {
       snprintf(R.why, sizeof R.why, "librccl could not be loaded: %s", dlerror());
       return;
@@ -93,7 +106,10 @@ Rccl *rccl() {
     if (!ok) {
       dlclose(R.handle);
       R.handle = nullptr;
+      return;
     }
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(R.CommInitRank), &info) && info.dli_fname) snprintf(R.path, sizeof R.path, "%s", info.dli_fname);
   });
   return R.handle ? &R : nullptr;
 }
@@ -368,6 +384,16 @@ extern "C" int brk_comm_destroy(void *comm) {
   if (!R) return rccl_missing();
   NCCL_TRY(R, R->CommDestroy(static_cast<ncclComm_t>(comm)));
   return BRK_OK;
+}
+
+// the RCCL library the transport is bound to (file name as dladdr reports it), or NULL + error when none can be bound
+extern "C" const char *brk_comm_library(void) {
+  Rccl *R = rccl();
+  if (!R) {
+    (void)rccl_missing();
+    return nullptr;
+  }
+  return R->path;
 }
 
 extern "C" int brk_comm_rank(void *comm, int *rank, int *nranks) {

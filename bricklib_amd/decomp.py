@@ -217,6 +217,13 @@ class Comm:
         self._h, self.rank, self.size = handle, rank, size
 
     @staticmethod
+    def library():
+        """file name of the RCCL library the C-ABI transport is bound to (an RCCL already mapped into the process -- torch's -- is
+        preferred over loading a second one), or None when none can be bound"""
+        p = lib.brk_comm_library()
+        return p.decode() if p else None
+
+    @staticmethod
     def unique_id():
         buf = C.create_string_buffer(128)
         check(lib.brk_comm_unique_id(buf))
@@ -420,8 +427,10 @@ class Exchanger:
 
     def exchange(self, stream=None):
         """Asynchronous on `stream` (default: current stream) for device storages."""
+        from .timing import marker
         if self._view is not None and (self.comm is not None or not self.plan.msgs):
-            check(lib.brk_exchange_run(self._view, self.comm._h if self.comm is not None else None, _stream(stream)))
+            with marker("exchange"):
+                check(lib.brk_exchange_run(self._view, self.comm._h if self.comm is not None else None, _stream(stream)))
             return
         for st in range(self.nstages):
             self.exchange_begin(stream, st)

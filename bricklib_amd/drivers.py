@@ -12,6 +12,7 @@ import torch
 from .brick import grid_to_device
 from .order import decomp_lists, trapezoid_lists
 from .stencils import Zigzag, apply_stencil, stencil_iters
+from .timing import marker
 
 
 class SweepLists:
@@ -41,6 +42,10 @@ def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, ove
     zz = Zigzag()
 
     def sweep(src, dst, which):
+        with marker("calc:" + which):
+            _sweep(src, dst, which)
+
+    def _sweep(src, dst, which):
         rev = zigzag and zz.turn()
         if lists is not None:
             apply_stencil(stencil, src, dst, ids=getattr(lists, which), coeff=coeff, stream=main, kpaired=lists.kpaired, reverse=rev)

@@ -55,3 +55,56 @@ def time_mpi(func, iters, reset=None):
     for _ in range(iters):
         func()
     return (time.perf_counter() - st) / iters
+
+
+# ---- markers and per-phase statistics of the distributed drivers ------------------------------------------------------------------
+class marker:
+    """`with marker("pack"): ...` -- a roctx range around a phase of the exchange / sweep cycle, so that
+    `rocprofv3 --marker-trace --kernel-trace -- python bench.py --gpus N ...` shows which kernels and RCCL calls belong to which
+    phase.  PyTorch on ROCm routes torch.cuda.nvtx to roctx; without it the ranges cost nothing."""
+    _push = _pop = None
+    _ready = False
+
+    def __init__(self, name):
+        self.name = name
+        if not marker._ready:
+            marker._ready = True
+            try:
+                import torch
+                torch.cuda.nvtx.range_push("brk")
+                torch.cuda.nvtx.range_pop()
+                marker._push, marker._pop = torch.cuda.nvtx.range_push, torch.cuda.nvtx.range_pop
+            except Exception:
+                marker._push = marker._pop = None
+
+    def __enter__(self):
+        if marker._push:
+            marker._push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if marker._pop:
+            marker._pop()
+        return False
+
+
+def rank_statistics(value, world=1, group=None):
+    """min / avg / max / sigma of one number per rank, on every rank -- the reference's mpi_statistics (include/brick-mpi.h:758-793:
+    sample standard deviation).  COLLECTIVE when world > 1: every rank of the torch.distributed group must call it (a one-rank
+    run nested inside a larger job -- the scaling base of bench.py -- passes world = 1 and gathers nothing)."""
+    import math
+    vals = [float(value)]
+    if world > 1:
+        import torch.distributed as dist
+        box = [None] * dist.get_world_size(group)
+        dist.all_gather_object(box, float(value), group=group)
+        vals = [float(v) for v in box]
+    n = len(vals)
+    avg = sum(vals) / n
+    var = sum((v - avg) ** 2 for v in vals) / (n - 1) if n > 1 else 0.0
+    return {"min": min(vals), "avg": avg, "max": max(vals), "sigma": math.sqrt(var)}
+
+
+def format_stats(name, s, unit="ms"):
+    """one line in the reference's format (weak/main.cpp:271-289: `calc [min, avg, max] (sigma: s)`)"""
+    return "%s [%.6g, %.6g, %.6g] (σ: %.6g) %s" % (name, s["min"], s["avg"], s["max"], s["sigma"], unit)

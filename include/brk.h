@@ -61,7 +61,8 @@ enum { BRK_7PT_COEFF = 0, BRK_27PT_COEFF = 1, BRK_MPI7 = 2, BRK_MPI13 = 3, BRK_M
 const char *brk_last_error(void);
 /* version of this ABI: 1000 + additions (1001: brk_stencil_apply_taps, 1002: the fused double-sweep stencil ids,
  * 1003: the ghost-zone exchange: brk_xplan_*, brk_exchange_*, brk_comm_*; 1004: brk_adjacency_register / _release;
- * 1005: brk_stencil_apply_{range,list,box}_ex with BRK_SWEEP_* flags) */
+ * 1005: brk_stencil_apply_{range,list,box}_ex with BRK_SWEEP_* flags; 1006: brk_comm_library, the development knob
+ * brk_set_variant is no longer part of the ABI) */
 int brk_abi_version(void);
 /* radius / number of coefficients / communication-avoiding sweeps per exchange (ST_ITER, fake.h:39-344) */
 int brk_stencil_radius(int stencil_id);
@@ -305,6 +306,10 @@ int brk_comm_unique_id(void *id128);
 int brk_comm_init_rank(void **nccl_comm, int nranks, const void *id128, int rank);
 int brk_comm_destroy(void *nccl_comm);
 int brk_comm_rank(void *nccl_comm, int *rank, int *nranks);
+/* Which RCCL the transport is bound to: the file name of the library that answers ncclCommInitRank (an RCCL the process has
+ * mapped already -- e.g. the one PyTorch ships -- is preferred over loading a second instance), or NULL when none can be bound
+ * (brk_last_error says why).  Replaces nothing in the reference (MPI is linked there); it exists so that a run can record it. */
+const char *brk_comm_library(void);
 
 /* Strong scaling bookkeeping (include/zmort.h:18-105, strong/args.cpp:36-56,104-113) */
 uint64_t brk_zmort_get(uint64_t id, uint64_t d);

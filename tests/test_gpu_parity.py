@@ -1100,6 +1100,12 @@ def test_bench_gpus2_starts_its_own_ranks_weak():
     assert d["scaling_base"]["value"] > 0 and d["scaling_efficiency"] > 0
     assert c["conservation_rel_drift"] <= 1e-12
     assert c["exchange_self_check"]["passed"] and c["transport"] == "gloo-staged" and c["messages_per_exchange"] >= 1
+    # round 4: the reference's per-phase lines (weak/main.cpp:271-289) in the JSON line, {min, avg, max, sigma} over the ranks
+    ph = c["phases"]
+    for k in ("pack_ms", "transport_ms", "unpack_ms", "calc_ms", "host_call_ms"):
+        assert set(ph[k]) == {"min", "avg", "max", "sigma"} and ph[k]["min"] <= ph[k]["avg"] <= ph[k]["max"], (k, ph[k])
+    assert ph["calc_ms"]["avg"] > 0 and ph["transport_ms"]["avg"] > 0 and ph["cycle_ms_timed"] > 0 and ph["exposed_exchange_ms"] >= 0
+    assert "calc [" in err and "transport [" in err and "σ" in err
 
 
 @pytest.mark.timeout(600)
@@ -1110,6 +1116,7 @@ def test_bench_gpus2_starts_its_own_ranks_strong():
     c = d["config"]
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and c["workload"] == "strong-mpi13pt-128-32" and c["subdomains_per_rank"] == 32
     assert c["conservation_rel_drift"] <= 1e-12 and c["remote_bytes_per_rank"] > 0
+    assert c["phases"]["calc_ms"]["avg"] > 0 and c["phases"]["pack_ms"]["max"] >= c["phases"]["pack_ms"]["min"] > 0
 
 
 @pytest.mark.timeout(600)
@@ -1126,6 +1133,10 @@ def test_bench_transport_auto_falls_back_to_torch():
     d2, _ = _bench_line(base + ["--transport", "auto"])
     c2 = d2["config"]
     assert c2["transport"].startswith("abi") and c2["transport_fallback_reason"] is None and c2["exchange_self_check"]["passed"]
+    # ONE RCCL in the process: the C-ABI transport binds to the library torch has already mapped (round 4, brk_comm_library)
+    import os
+    assert c2["rccl_library"] and "rccl" in c2["rccl_library"]
+    assert os.path.realpath(c2["rccl_library"]).startswith(os.path.realpath(os.path.dirname(torch.__file__))) or "rocm" in c2["rccl_library"], c2["rccl_library"]
     assert c2["conservation_rel_drift"] <= 1e-12 and c2["messages_per_exchange"] == c["messages_per_exchange"]
 
 
