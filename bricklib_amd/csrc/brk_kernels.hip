@@ -86,6 +86,19 @@ __global__ __launch_bounds__(64 * WPW) void k_taps(const uint32_t *__restrict__ 
   taps_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, b, tp, threadIdx.x & 63);
 }
 
+// star-shaped stencil given as data, radius 3 or 4 (brk_stencil_apply_taps): one wave per workgroup (27.5 KiB of LDS per wave)
+template <int R>
+__global__ __launch_bounds__(64) void k_star_taps(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
+                                                  size_t step, const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, StarTaps tp) {
+  __shared__ double lds[StarTapTile<R>::ELEMS];
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t slot = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (slot >= n) return;
+  const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
+  if (b == BRK_LIST_SKIP) return;
+  star_taps_brick<R>(lds, adj, in, out, step, b, tp, threadIdx.x & 63);
+}
+
 // ================================================================================================================
 // Region copies (pack / unpack / same-GPU halo links).  grid = (chunks, links); 16-B lanes, 64 KiB per block.
 // ================================================================================================================
@@ -670,21 +683,45 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
   if (ntaps == 0 || ntaps > (uint32_t)kMaxTaps || !offsets_host || !weights_host)
     return brk_fail(BRK_EINVAL, "1..%d taps with host offset and weight arrays expected (got %u)", kMaxTaps, ntaps);
   if (n == 0) return BRK_OK;
-  Taps tp;
-  tp.n = (int)ntaps;
-  tp.radius = 1;
-  for (uint32_t t = 0; t < ntaps; ++t)
+  // shape of the table: cube-shaped taps inside the 125-point cube (|offset| <= 2 on every axis) run on the staged (8+2R)^3 tile;
+  // star-shaped taps (one axis per tap) reach radius 4 on the star staging; anything else has no path
+  int maxabs = 0;
+  bool star = true;
+  for (uint32_t t = 0; t < ntaps; ++t) {
+    int nonzero = 0;
     for (int a = 0; a < 3; ++a) {
       const int o = offsets_host[3 * t + a];
-      if (o < -2 || o > 2) return brk_fail(BRK_EINVAL, "tap %u: offset %d on axis %d outside [-2,2]", t, o, a);
-      if (o < -1 || o > 1) tp.radius = 2;
+      maxabs = std::max(maxabs, o < 0 ? -o : o);
+      nonzero += o != 0;
     }
+    star = star && nonzero <= 1;
+  }
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (maxabs > 2) {
+    if (!star || maxabs > 4)
+      return brk_fail(BRK_EINVAL, "taps reach offset %d: cube-shaped tables are limited to [-2,2] per axis, star-shaped ones (one axis per tap) to [-4,4]", maxabs);
+    if (ntaps > (uint32_t)kMaxStarTaps) return brk_fail(BRK_EINVAL, "%u star taps exceed %d", ntaps, kMaxStarTaps);
+    StarTaps sp;
+    std::memset(&sp, 0, sizeof sp);
+    sp.n = (int)ntaps;
+    for (uint32_t t = 0; t < ntaps; ++t) {
+      const int di = offsets_host[3 * t], dj = offsets_host[3 * t + 1], dk = offsets_host[3 * t + 2];
+      sp.axis[t] = dk ? 2 : (dj ? 1 : 0);
+      sp.off[t] = dk ? dk : (dj ? dj : di);
+      sp.w[t] = weights_host[t];
+    }
+    hipLaunchKernelGGL((k_star_taps<4>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, sp);
+    HIP_TRY(hipGetLastError());
+    return BRK_OK;
+  }
+  Taps tp;
+  tp.n = (int)ntaps;
+  tp.radius = maxabs > 1 ? 2 : 1;
   for (uint32_t t = 0; t < ntaps; ++t) {
     const int di = offsets_host[3 * t], dj = offsets_host[3 * t + 1], dk = offsets_host[3 * t + 2];
     tp.rel[t] = tp.radius == 1 ? tap_rel<1>(di, dj, dk) : tap_rel<2>(di, dj, dk);
     tp.w[t] = weights_host[t];
   }
-  hipStream_t st = static_cast<hipStream_t>(s);
   const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
   if (tp.radius == 1) hipLaunchKernelGGL((k_taps<1, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);
   else hipLaunchKernelGGL((k_taps<2, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);

@@ -68,8 +68,9 @@ class Zigzag:
 
 
 def apply_taps(taps, bIn, bOut, ids=None, brick_range=None, stream=None):
-    """A linear stencil given as data (brk_stencil_apply_taps): taps = [((di, dj, dk), weight), ...] with offsets in
-    [-2, 2], applied in list order; e.g. the output of bricklib_amd.spec.load_spec(...).taps(constants)."""
+    """A linear stencil given as data (brk_stencil_apply_taps): taps = [((di, dj, dk), weight), ...], applied in list order -- any
+    table with offsets in [-2, 2], or a star-shaped one (one axis per tap) with offsets in [-4, 4]; e.g. the output of
+    bricklib_amd.spec.load_spec(...).taps(constants)."""
     off = np.ascontiguousarray([list(o) for o, _ in taps], dtype=np.int32).reshape(-1)
     w = np.ascontiguousarray([float(x) for _, x in taps], dtype=np.float64)
     offp, wp = off.ctypes.data_as(C.POINTER(C.c_int32)), w.ctypes.data_as(C.POINTER(C.c_double))

@@ -66,6 +66,16 @@ __global__ void lap19_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Bri
   brick("lap19.py", VSVEC, (BDIM), (VFOLD), b);
 }
 
+// ... and one that reaches beyond the 125-point cube: examples/star37.py, a radius-3 star with up-/downwind weights (star-shaped
+// scripts are provided up to radius 4)
+__global__ void star37_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Brick3D bOut, bElem *coeff) {
+  long tk = GB + hipBlockIdx_z;
+  long tj = GB + hipBlockIdx_y;
+  long ti = GB + hipBlockIdx_x;
+  unsigned b = grid[tk][tj][ti];
+  brick("star37.py", VSVEC, (BDIM), (VFOLD), b);
+}
+
 int main() {
   bElem *coeff = (bElem *)malloc(COEFF_SIZE * sizeof(bElem));
   {
@@ -184,6 +194,25 @@ int main() {
     hipLaunchKernelGGL(lap19_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
     gpuCheck(hipDeviceSynchronize());
     check("brick() lap19 kernel (script read as data)");
+  }
+  // (5) a user-written radius-3 star (star37.py) through the star-shaped tap path
+  {
+#pragma omp parallel for collapse(2)
+    for (long k = PADDING + GZ; k < PADDING + GZ + N; ++k)
+      for (long j = PADDING + GZ; j < PADDING + GZ + N; ++j)
+        for (long i = PADDING + GZ; i < PADDING + GZ + N; ++i) {
+          bElem acc = coeff[0] * arr_in[k][j][i];
+          for (int d = 1; d <= 3; ++d) {
+            acc += coeff[d] * (arr_in[k][j][i + d] + arr_in[k][j + d][i] + arr_in[k + d][j][i]);
+            acc += coeff[3 + d] * (arr_in[k][j][i - d] + arr_in[k][j - d][i] + arr_in[k - d][j][i]);
+          }
+          arr_out[k][j][i] = acc;
+        }
+    Brick3D dIn(binfo_dev, bstorage_dev, 0), dOut(binfo_dev, bstorage_dev, bsize);
+    dim3 block(NB, NB, NB), thread(64);
+    hipLaunchKernelGGL(star37_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
+    gpuCheck(hipDeviceSynchronize());
+    check("brick() star37 kernel (radius-3 star script read as data)");
   }
   return 0;
 }

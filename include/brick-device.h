@@ -766,6 +766,129 @@ __device__ __forceinline__ void brick_apply_taps_static(const uint32_t *adj, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// STAR-shaped stencils given as data, radius up to 4: every tap moves along ONE axis (what a user-written radius-3 or
+// radius-4 finite-difference script is; the reference's generator takes any script, codegen/st/codegen/base.py:678).  Staging
+// as star_brick (k-column in registers, TJ / TI sub-tiles); with taps known only at run time the k-column goes to LDS as
+// well (TK[8+2R][64]) so that a tap is ONE ds_read at base(axis) + offset + k * stride(axis).  General path, not a tuned one.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMaxStarTaps = 64;
+struct StarTaps {
+  int n;
+  int axis[kMaxStarTaps]; // 0 = i, 1 = j, 2 = k (a centre tap is axis 0, offset 0)
+  int off[kMaxStarTaps];  // -R .. R
+  double w[kMaxStarTaps];
+};
+
+template <int R>
+struct StarTapTile {
+  using TL = StarTile<R>;
+  static constexpr int TK = TL::ELEMS;                 // k-extended column planes behind the TJ / TI sub-tiles
+  static constexpr int ELEMS = TL::ELEMS + (8 + 2 * R) * 64;
+};
+
+// loads + staging shared by the two star-tap forms; col[] = the lane's k-column, [R, R+8) its own planes
+template <int R>
+__device__ __forceinline__ void star_stage(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in, size_t step,
+                                           uint32_t b, int lane, double (&col)[8 + 2 * R]) {
+  using TL = StarTile<R>;
+  const int hi = lane >> 3, lo = lane & 7;
+  const uint32_t arow = adj[(size_t)b * 27 + (lane < 27 ? lane : 13)];
+  const uint32_t n_km = __builtin_amdgcn_readlane(arow, adj_slot(-1, 0, 0)), n_kp = __builtin_amdgcn_readlane(arow, adj_slot(1, 0, 0));
+  const uint32_t n_jm = __builtin_amdgcn_readlane(arow, adj_slot(0, -1, 0)), n_jp = __builtin_amdgcn_readlane(arow, adj_slot(0, 1, 0));
+  const uint32_t n_im = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, -1)), n_ip = __builtin_amdgcn_readlane(arow, adj_slot(0, 0, 1));
+  const double *self = in + (size_t)b * step;
+  const double *p_km = in + (size_t)n_km * step, *p_kp = in + (size_t)n_kp * step;
+  const double *p_jm = in + (size_t)n_jm * step, *p_jp = in + (size_t)n_jp * step;
+  const double *p_im = in + (size_t)n_im * step, *p_ip = in + (size_t)n_ip * step;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) col[R + k] = self[k * 64 + lane];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    col[r] = p_km[(8 - R + r) * 64 + lane];
+    col[R + 8 + r] = p_kp[r * 64 + lane];
+  }
+  double fjm[R], fjp[R], fim[R], fip[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    fjm[r] = p_jm[hi * 64 + (8 - R + r) * 8 + lo];
+    fjp[r] = p_jp[hi * 64 + r * 8 + lo];
+    fim[r] = p_im[hi * 64 + lo * 8 + (8 - R + r)];
+    fip[r] = p_ip[hi * 64 + lo * 8 + r];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    tile[TL::tj(k, hi + R, lo)] = col[R + k];
+    tile[TL::ti(k, hi, lo + R)] = col[R + k];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    tile[TL::tj(hi, r, lo)] = fjm[r];
+    tile[TL::tj(hi, R + 8 + r, lo)] = fjp[r];
+    tile[TL::ti(hi, lo, r)] = fim[r];
+    tile[TL::ti(hi, lo, R + 8 + r)] = fip[r];
+  }
+}
+
+// taps as run-time data (brk_stencil_apply_taps for star-shaped tables of radius 3 or 4)
+template <int R>
+__device__ __forceinline__ void star_taps_brick(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                                double *__restrict__ out, size_t step, uint32_t b, const StarTaps &tp, int lane) {
+  using TL = StarTile<R>;
+  using TT = StarTapTile<R>;
+  const int hi = lane >> 3, lo = lane & 7;
+  double col[8 + 2 * R];
+  star_stage<R>(tile, adj, in, step, b, lane, col);
+#pragma unroll
+  for (int q = 0; q < 8 + 2 * R; ++q) tile[TT::TK + q * 64 + lane] = col[q];
+  wave_lds_sync();
+  // per axis: address of the lane's centre cell in plane 0 and the stride from one plane to the next
+  const int base[3] = {TL::ti(0, hi, lo + R), TL::tj(0, hi + R, lo), TT::TK + R * 64 + lane};
+  const int tapstride[3] = {1, 8, 64};
+  const int kstride[3] = {8 * TL::PI, TL::T * 8, 64};
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+#pragma unroll 1
+  for (int t = 0; t < tp.n; ++t) {
+    const int a = tp.axis[t];
+    const int o = (a == 0 ? base[0] : (a == 1 ? base[1] : base[2])) + tp.off[t] * (a == 0 ? tapstride[0] : (a == 1 ? tapstride[1] : tapstride[2]));
+    const int ks = a == 0 ? kstride[0] : (a == 1 ? kstride[1] : kstride[2]);
+    const double w = tp.w[t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += w * tile[o + k * ks];
+  }
+  double *dst = out + (size_t)b * step;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
+}
+
+// the same with the tap table known at compile time (what tools/brkscatter emits for a star-shaped script of radius 3 or 4):
+// fully unrolled, the k-taps straight from the register column
+template <int R, int NTAPS, int MAXW = 4>
+__device__ __forceinline__ void brick_apply_star_taps_static(const uint32_t *adj, const double *in, double *out, size_t step, uint32_t b,
+                                                             const int (&axis)[NTAPS], const int (&off)[NTAPS], const double (&w)[NTAPS]) {
+  using TL = StarTile<R>;
+  __shared__ double lds[MAXW * TL::ELEMS];
+  const int lane = threadIdx.x & 63, hi = lane >> 3, lo = lane & 7;
+  double *tile = lds + (threadIdx.x >> 6) * TL::ELEMS;
+  b = __builtin_amdgcn_readfirstlane(b);
+  double col[8 + 2 * R];
+  star_stage<R>(tile, adj, in, step, b, lane, col);
+  wave_lds_sync();
+  double *dst = out + (size_t)b * step;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double acc = 0.0;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+      const double v = axis[t] == 2 ? col[R + k + off[t]] : (axis[t] == 1 ? tile[TL::tj(k, hi + R + off[t], lo)] : tile[TL::ti(k, hi, lo + R + off[t])]);
+      acc += w[t] * v;
+    }
+    store_result(&dst[k * 64 + lane], acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Entry points for user kernels (one wave per brick, any number of waves per block up to MAXW).
 // in/out: field base pointers (Brick::dat), step: Brick::step, adj: BrickInfo::adj as uint32_t[nbricks][27],
 // coeff: DEVICE pointer to the coefficient vector of the stencil (see brk.h), b: wave-uniform brick id.

@@ -143,8 +143,11 @@ int brk_adjacency_release(const uint32_t *adj_dev);
 
 /* A linear stencil given as data -- the capability of the reference's code generator for scripts that are not one of the
  * built-in ones (codegen/vecscatter evaluating stencils/<name>.py; bricklib_amd/spec.py reads such scripts into this form):
- *   out[p] = sum_t weights[t] * in[p + (offsets[3t], offsets[3t+1], offsets[3t+2])]   (i, j, k offsets, each in [-2,2],
- *   1 <= ntaps <= 125, taps added in list order).  Bricks: brick_ids_dev[0..n) when non-NULL (BRK_LIST_SKIP allowed), else
+ *   out[p] = sum_t weights[t] * in[p + (offsets[3t], offsets[3t+1], offsets[3t+2])]   (i, j, k offsets; taps added in list
+ *   order).  Two shapes: any table inside the 125-point cube (every offset in [-2,2], 1 <= ntaps <= 125), or a STAR-shaped
+ *   table -- every tap moves along one axis only -- with offsets up to [-4,4] (1 <= ntaps <= 64): a user-written radius-3 or
+ *   radius-4 finite-difference script (the reference's generator takes any script, codegen/st/codegen/base.py:678;
+ *   stencils/mpi25pt.py is radius 4).  Cube-shaped taps beyond radius 2 are refused with BRK_EINVAL.  Bricks: brick_ids_dev[0..n) when non-NULL (BRK_LIST_SKIP allowed), else
  *   ids first..first+n-1.  General path: one LDS read + FMA per tap and point, not tuned like the built-in stencils. */
 int brk_stencil_apply_taps(const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
                            const uint32_t *brick_ids_dev, uint32_t first, uint32_t n, uint32_t ntaps,

@@ -168,6 +168,17 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     }
     return;
   }
+  if (name.find("k_star_taps<") != std::string::npos) { // (adj, in, out, step, ids, first, n, StarTaps)
+    const brk::StarTaps t = arg<brk::StarTaps>(args, 7);
+    std::vector<int> off;
+    for (int q = 0; q < t.n; ++q) off.insert(off.end(), {t.axis[q] == 0 ? t.off[q] : 0, t.axis[q] == 1 ? t.off[q] : 0, t.axis[q] == 2 ? t.off[q] : 0});
+    const std::vector<uint32_t> list = checked_list(arg<const uint32_t *>(args, 0), arg<const double *>(args, 1), arg<double *>(args, 2), arg<size_t>(args, 3),
+                                                    arg<const uint32_t *>(args, 4), arg<uint32_t>(args, 5), arg<uint32_t>(args, 6));
+    if (!list.empty())
+      orc_brick_taps(arg<const uint32_t *>(args, 0), arg<const double *>(args, 1), arg<double *>(args, 2), arg<size_t>(args, 3), list.data(), (long)list.size(), t.n,
+                     off.data(), t.w);
+    return;
+  }
   const bool s7 = name.find("k_s7_wg<") != std::string::npos, swg = name.find("k_star_wg<") != std::string::npos,
              skp = name.find("k_star_kp<") != std::string::npos, cd = name.find("k_cube_dense<") != std::string::npos,
              tp = name.find("k_taps<") != std::string::npos;

@@ -169,6 +169,11 @@ static int launches() {
     REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 3, 6, off, w, nullptr) == BRK_OK);
     const int32_t far[] = {9, 0, 0};
     REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 1, 1, 1, far, w, nullptr) != BRK_OK);
+    // star-shaped tables reach radius 4; cube-shaped ones stop at 2
+    const int32_t star4[] = {0, 0, 0, 4, 0, 0, -3, 0, 0, 0, 4, 0, 0, -4, 0, 0, 0, 3};
+    REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 3, 6, star4, w, nullptr) == BRK_OK);
+    const int32_t cube3[] = {3, 1, 0};
+    REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 1, 1, cube3, w, nullptr) != BRK_OK);
   }
   // array <-> brick, compare
   {

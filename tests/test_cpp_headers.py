@@ -140,6 +140,7 @@ def test_example_driver_runs():
     assert "brick() kernel: result match" in out and "brk_stencil_apply_list: result match" in out, out
     assert "brick() cond kernel: result match" in out, out
     assert "brick() lap19 kernel (script read as data): result match" in out, out   # user-written script, generic tap path
+    assert "brick() star37 kernel (radius-3 star script read as data): result match" in out, out   # beyond the 125-point cube: star path
     out2 = subprocess.run([os.path.join(ROOT, "examples", "dev_shl_check")], check=True, stdout=subprocess.PIPE).stdout.decode()
     assert "dev_shl: ok" in out2, out2
 

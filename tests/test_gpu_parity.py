@@ -850,14 +850,27 @@ def _taps_cases(oracle):
                       for di in range(-r, r + 1)]
     c27, c125 = cube(1), cube(2)
     lopsided = [c125[q] for q in rng.choice(125, 19, replace=False)]
-    return {"seven": seven, "cube27": c27, "cube125": c125, "lopsided19": lopsided, "single-shifted": [((2, -2, 1), 1.0)]}
+    # star-shaped tables beyond the 125-point cube (round 4): a radius-3 and a radius-4 star with their own weights (NOT
+    # mpi25pt's five classes), a lopsided one, and single far taps
+    def star(r):
+        t = [((0, 0, 0), float(rng.uniform(-1, 1)))]
+        for a in range(3):
+            for o in range(-r, r + 1):
+                if o:
+                    off = [0, 0, 0]
+                    off[a] = o
+                    t.append((tuple(off), float(rng.uniform(-1, 1))))
+        return t
+    return {"seven": seven, "cube27": c27, "cube125": c125, "lopsided19": lopsided, "single-shifted": [((2, -2, 1), 1.0)],
+            "star-r3": star(3), "star-r4": star(4), "star-lopsided": [((4, 0, 0), 0.5), ((0, -3, 0), -0.25), ((0, 0, 4), 2.0), ((0, 0, -4), 1.0), ((0, 0, 0), -1.0)],
+            "far-i": [((-4, 0, 0), 1.0)], "far-k": [((0, 0, 3), 1.0)]}
 
 
-@pytest.mark.parametrize("case", ["seven", "cube27", "cube125", "lopsided19", "single-shifted"])
+@pytest.mark.parametrize("case", ["seven", "cube27", "cube125", "lopsided19", "single-shifted", "star-r3", "star-r4", "star-lopsided", "far-i", "far-k"])
 def test_stencil_given_as_taps(oracle, dev, case):
-    """brk_stencil_apply_taps: arbitrary linear stencils inside the 125-point cube, list (with skipped
-    entries) and range forms, against the oracle's accessor-semantics evaluation; the 7-point taps also against the
-    built-in kernel."""
+    """brk_stencil_apply_taps: arbitrary linear stencils inside the 125-point cube and star-shaped ones up to
+    radius 4 (the reference generator takes any script, codegen/st/codegen/base.py:678), list (with skipped entries) and range
+    forms, against the oracle's accessor-semantics evaluation; the 7-point taps also against the built-in kernel."""
     from bricklib_amd.order import LIST_SKIP, tiled
     from bricklib_amd.stencils import apply_taps
     taps = _taps_cases(oracle)[case]
@@ -895,7 +908,7 @@ def test_taps_argument_checks(dev):
     from bricklib_amd.stencils import apply_taps
     grid, info = bl.init_grid((4, 4, 4), dev)
     st, so = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(2))
-    for bad in ([((3, 0, 0), 1.0)], [((0, 0, 0), 1.0)] * 126):
+    for bad in ([((5, 0, 0), 1.0)], [((3, 1, 0), 1.0)], [((0, 0, 0), 1.0)] * 126, [((4, 0, 0), 1.0)] * 65):
         with pytest.raises(BrkError):
             apply_taps(bad, bl.Brick(info, st, 0), bl.Brick(info, so, 0), brick_range=(0, 1))
 
