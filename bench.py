@@ -272,12 +272,14 @@ def make_comm(args, world, dev):
 
 def exchange_self_check(d, st, ex, rank, world, dev, label):
     """One exchange on recognisable data BEFORE anything is timed (reference rule, include/brick-mpi.h:476-491: ghost run i <- skin
-    run i of the rank behind ghost[i].neighbor): every rank writes rank * 2^20 + brick id into its surface bricks and -1 into its
+    run i of the rank behind ghost[i].neighbor): every rank writes rank * nbricks + brick id into its surface bricks (all ranks have the same decomposition; exact in fp64
+    far beyond any size that fits a GPU) and -1 into its
     ghost bricks, exchanges once and checks every ghost run against the ids its peer must have sent.  Returns None, or a text naming
     the first wrong run.  A mis-routed or mis-ordered run becomes a non-zero exit, not a silent drift."""
     s0, s1, s2 = d.sep_pos
+    stride = int(s2)                       # ids of one rank live in [0, nbricks): rank * nbricks + id decodes unambiguously
     v = st.dat.view(-1, st.step)
-    v[s0:s1] = (torch.arange(s0, s1, device=dev, dtype=torch.float64) + float(rank << 20))[:, None]
+    v[s0:s1] = (torch.arange(s0, s1, device=dev, dtype=torch.float64) + float(rank * stride))[:, None]
     v[s1:s2] = -1.0
     torch.cuda.synchronize()
     ex.exchange(torch.cuda.current_stream())
@@ -285,7 +287,7 @@ def exchange_self_check(d, st, ex, rank, world, dev, label):
     want = np.empty(s2 - s1, dtype=np.float64)
     for g, k in zip(d.ghost, d.skin):
         src = d.rank_map[g["neighbor"]]
-        want[g["pos"] - s1:g["pos"] - s1 + g["len"]] = np.arange(k["pos"], k["pos"] + g["len"], dtype=np.float64) + float(src << 20)
+        want[g["pos"] - s1:g["pos"] - s1 + g["len"]] = np.arange(k["pos"], k["pos"] + g["len"], dtype=np.float64) + float(src * stride)
     bad = (v[s1:s2] != torch.from_numpy(want).to(dev)[:, None]).any(dim=1).cpu().numpy()
     if not bad.any():
         return None
@@ -294,7 +296,7 @@ def exchange_self_check(d, st, ex, rank, world, dev, label):
         if g["pos"] <= b < g["pos"] + g["len"]:
             got = float(v[b, 0].item())
             return (f"exchange self-check ({label}) FAILED on rank {rank}: ghost run {q} (neighbor set {g['neighbor']:#x}, from rank "
-                    f"{d.rank_map[g['neighbor']]}), brick {b}: holds {got:.0f} = rank {int(got) >> 20} brick {int(got) & 0xFFFFF}, "
+                    f"{d.rank_map[g['neighbor']]}), brick {b}: holds {got:.0f} = rank {int(got) // stride if got >= 0 else -1} brick {int(got) % stride if got >= 0 else -1}, "
                     f"expected rank {d.rank_map[g['neighbor']]} brick {d.skin[q]['pos'] + b - g['pos']}; {int(bad.sum())} ghost bricks wrong")
     return f"exchange self-check ({label}) FAILED on rank {rank}: brick {b} outside every ghost run"
 
@@ -616,7 +618,8 @@ def run_weak(args, bl, dev, rank, world):
             err = exchange_self_check(d, stA, ex, rank, world, dev, label)
         except Exception as e:
             err = f"exchange self-check ({label}) raised on rank {rank}: {e!r}"
-        wd_.cancel()
+        finally:
+            wd_.cancel()
         flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
@@ -628,8 +631,13 @@ def run_weak(args, bl, dev, rank, world):
         if err:
             sys.stderr.write(err + "\n")
         fallback_reason = err or "the self-check failed on another rank"
-        torch.cuda.synchronize()
-        comm.destroy()
+        # the communicator whose exchange just failed may still have work stuck on the device: bound the wait for it
+        wd_ = _watchdog(min(args.watchdog_seconds, 240.0), rank, "destroying the C-ABI communicator after a failed self-check")
+        try:
+            torch.cuda.synchronize()
+            comm.destroy()
+        finally:
+            wd_.cancel()
         comm, transport = None, "torch"
         ex = make_exchanger(None)
         err, any_bad = checked_exchange(transport)

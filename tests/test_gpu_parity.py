@@ -1277,6 +1277,58 @@ def test_strong_cycle_baseline_shape_512_128(oracle, dev):
         assert err <= TOL, (q, err)
 
 
+@pytest.mark.timeout(900)
+def test_strong_cycle_full_baseline_1024_128(oracle, dev):
+    """BASELINE config 5 at its FULL size on one GPU (the share of all 8 ranks): global 1024^3 in 512 subdomains of 128^3, 13-point
+    stencil, one exchange + ST_ITER = 4 sweeps (strong/main.cu:397-510).  The input is a hash of the GLOBAL periodic cell
+    coordinate, so any neighbourhood can be rebuilt on the host: six sampled subdomains -- the corners of the Z-Morton cube that
+    wrap around the periodic domain, and inner ones -- are compared cell by cell with 4 oracle sweeps of their (128 + 16)^3
+    neighbourhood (what the reference's -v validation does for every subdomain, strong/main.cpp:359-365,402-464), and the sum of
+    the whole field must be conserved to 1e-12."""
+    from bricklib_amd.strong import StrongRank
+    dom, sub = 1024, 128
+    free = torch.cuda.mem_get_info()[0]
+    if free < 48 * 2 ** 30:
+        pytest.skip("needs 48 GiB of free device memory")
+    sr = StrongRank(dom, sub, 0, 1, dev)
+    assert sr.nsub == 512 and sr.peers == []
+
+    def field(xp, z, y, x):           # the same integers on the device (torch) and on the host (numpy)
+        h = (x * 73856093) ^ (y * 19349663) ^ (z * 83492791)
+        h = ((h ^ (h >> 13)) & 0x7FFFFFFF) * 1274126177      # < 2^62: no wrap-around in either library
+        return ((h ^ (h >> 16)) & 0xFFFFF).astype(np.float64) / 1048576.0 if xp is np else ((h ^ (h >> 16)) & 0xFFFFF).to(torch.float64) / 1048576.0
+
+    view = sr.storages[0].dat.view(sr.nsub, sr.nb, 512)
+    view.zero_()
+    ar = torch.arange(sub, device=dev, dtype=torch.int64)
+    blk = torch.zeros((sub + 16,) * 3, dtype=torch.float64, device=dev)
+    for q in range(sr.nsub):
+        x, y, z = sr.origin(q)
+        blk[8:-8, 8:-8, 8:-8] = field(torch, (z + ar)[:, None, None], (y + ar)[None, :, None], (x + ar)[None, None, :])
+        bl.copyToBrick((sub + 16,) * 3, (0,) * 3, (0,) * 3, blk, sr.grid_dev, sr.sub_brick(0, q))
+    sum0 = float(view[:, 1:sr.d.sep_pos[1]].sum().item())
+    sr.exchange(None, torch.cuda.current_stream())
+    sr.sweeps("mpi13pt")
+    torch.cuda.synchronize()
+    view = sr.storages[0].dat.view(sr.nsub, sr.nb, 512)
+    assert abs(float(view[:, 1:sr.d.sep_pos[1]].sum().item()) - sum0) / sum0 <= 1e-12
+    coords = np.arange(-8, sub + 8, dtype=np.int64)
+    for q in (0, 7, 73, 255, 438, 511):
+        x, y, z = sr.origin(q)
+        cur = field(np, ((z + coords) % dom)[:, None, None], ((y + coords) % dom)[None, :, None], ((x + coords) % dom)[None, None, :])
+        cur = np.ascontiguousarray(np.broadcast_to(cur, (sub + 16,) * 3))
+        for s_ in range(1, 5):
+            nxt = np.zeros_like(cur)
+            oracle.array_stencil(ST_MPI13, cur, nxt, (2 * s_,) * 3, tuple(sub + 16 - 2 * s_ for _ in range(3)))
+            cur = nxt
+        got = torch.zeros((sub + 16,) * 3, dtype=torch.float64, device=dev)
+        bl.copyFromBrick((sub,) * 3, (0,) * 3, (8,) * 3, got, sr.grid_dev, sr.sub_brick(0, q))
+        err = np.abs(got[8:-8, 8:-8, 8:-8].cpu().numpy() - cur[8:-8, 8:-8, 8:-8]).max()
+        assert err <= TOL, (q, err)
+    del sr, view
+    torch.cuda.empty_cache()
+
+
 def test_registered_adjacency_box_form_is_bit_identical(oracle, dev):
     """brk_adjacency_register (the BrickInfo of init_grid / getBrickInfo registers its device table): the 7-point box kernels then
     skip the adjacency rows of bricks whose face neighbours are the predicted ones.  Same bits as the unregistered path -- also
