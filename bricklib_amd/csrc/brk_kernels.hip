@@ -765,7 +765,7 @@ extern "C" int brk_stencil_apply_box_ex(int id, const uint32_t *adj, const doubl
   // the k-halo lines in the 4-MiB L2 until the brick itself is swept (fabric reads 1.05 -> 0.73 GB, FETCH_SIZE 709 174 KB, traffic
   // 3.18 -> 2.53 GB per 512^3 sweep) but the sweep takes 0.500-0.508 ms instead of 0.493-0.495: the extra reads are served by the
   // Infinity Cache and are not what bounds the kernel, the shorter rows-in-flight window is (profiles/r03_d_25pt_rows_per_block.txt).
-  const bool kpair = id == BRK_MPI25; // the radius-4 star runs two bricks per wave over k-paired lists (k_star_kp, brk_starwg.hip)
+  const bool kpair = id == BRK_MPI25 || id == BRK_MPI13; // the stars march two k-consecutive bricks per wave over k-paired lists (k_star_km, brk_starwg.hip)
   if (int rc = box_list_locked(base, tot, lo, cnt, 8u, kpair, &e)) return rc;
   if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s, kpair, reverse)) return rc;
   HIP_TRY(hipEventRecord(e->last_use, static_cast<hipStream_t>(s)));

@@ -369,6 +369,12 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
 }
 
 
+#ifdef BRK_VARIANTS
+// ==== round-4 experiments, development builds only: two bricks per wave for the 7-point stencil.  Measured at 512^3, interleaved with
+// the default kernel (profiles/r04_a_7pt_two_bricks_per_wave.txt, r04_d_7pt_kmarch_one_tile.txt): two tiles, k- or j-paired lists,
+// 12 waves/CU 0.382 ms; one tile, k-march, 24 or 16 waves/CU 0.395-0.401 ms; default (one brick per wave, 24 waves/CU) 0.363-0.369 ms
+// on the same boxes.  The pairing that pays for the radius-2 and radius-4 stars (k_star_km) does not pay at radius 1: a 7-point wave
+// saves one of its twelve loads and pays with half the independent waves per CU.  Kept for A/B runs (brk_set_variant 7..12).
 // ---- two bricks per wave ------------------------------------------------------------------------------------------------------
 // A workgroup of NW waves takes 2 NW list entries -- a run A of NW entries and the run B behind it -- and wave w handles entry w of
 // both: everything the two bricks need is requested up front (twice the bytes in flight per wave), both are staged in their own
@@ -489,6 +495,127 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_s7_2t(const uint32_t *__restri
   }
 }
 
+
+// ---- two k-consecutive bricks per wave, one tile (the 7-point form of k_star_km, brk_starwg.hip) -------------------------------
+// A workgroup of NW waves takes 2 NW list entries: a run of NW i-neighbours and the run of their +k neighbours (k-paired lists with
+// runs of NW).  Wave w requests both bricks and everything brick 0 needs up front, requests the faces of brick 1 just before brick 0
+// is staged, computes brick 0, then brick 1 out of the same tile.  The k-face between the two never travels (11 instead of 12 loads
+// per brick), and brick 1's requests are in flight through brick 0's staging, barrier and arithmetic.  Groups that are not two full
+// k-linked runs (the workgroup votes) take one brick at a time.
+template <int KIND, int NW, int OCC>
+__global__ __launch_bounds__(64 * NW, OCC) void k_s7_km(const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                                        double *__restrict__ out, size_t step, const uint32_t *__restrict__ ids,
+                                                        uint32_t first, uint32_t n, Coeffs cf, const uint32_t *__restrict__ faces) {
+  __shared__ double lds[NW * kTile];
+  __shared__ uint32_t vote[NW];
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + wg_in_xcd(cf, per_xcd);
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 3, lo = lane & 7;
+  double *tile = lds + w * kTile;
+  auto entry = [&](uint32_t sl) -> uint32_t { return sl < n ? __builtin_amdgcn_readfirstlane(ids ? ids[sl] : first + sl) : BRK_LIST_SKIP; };
+  auto u = [](uint32_t x) { return __builtin_amdgcn_readfirstlane(x); };
+  const uint32_t slot0 = wg * 2 * NW + w, slot1 = slot0 + NW;
+  const uint32_t b0 = entry(slot0), b1 = entry(slot1);
+  bool chain = b0 != BRK_LIST_SKIP && b1 != BRK_LIST_SKIP;
+  double own0[8], own1[8];
+  {
+    const gcptr s0 = sbase(in + (size_t)(chain ? b0 : 0u) * step), s1 = sbase(in + (size_t)(chain ? b1 : 0u) * step);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) own0[k] = s0[k * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) own1[k] = s1[k * 64 + lane];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const Nbr n0 = load_nbr(adj, faces, chain ? b0 : 0u), n1 = load_nbr(adj, faces, chain ? b1 : 0u);
+  chain = chain && u(n0.kp) == b1 && u(n1.km) == b0;
+  if (lane == 0) vote[w] = chain ? 1u : 0u;
+  __syncthreads();
+  bool fast = true;
+#pragma unroll
+  for (int q = 0; q < NW; ++q) fast = fast && vote[q] != 0u;
+
+  auto compute = [&](uint32_t b, const double (&own)[8], double km, double kp, bool s_im, bool s_ip) {
+    gptr dst = (gptr)(out + (size_t)b * step);
+    asm volatile("" : "+s"(dst));
+    const int o_jm = hi * 8 + lo, o_jp = (hi + 2) * 8 + lo;
+    const int o_im = lo > 0 ? (hi + 1) * 8 + lo - 1 : (s_im ? -kTile + (hi + 1) * 8 + 7 : 80 + hi);
+    const int o_ip = lo < 7 ? (hi + 1) * 8 + lo + 1 : (s_ip ? kTile + (hi + 1) * 8 : 88 + hi);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const double jm = tile[k * kPlane + o_jm], jp = tile[k * kPlane + o_jp];
+      const double im = tile[k * kPlane + o_im], ip = tile[k * kPlane + o_ip];
+      const double below = k == 0 ? km : own[k > 0 ? k - 1 : 0], above = k == 7 ? kp : own[k < 7 ? k + 1 : 7];
+      store_result(&dst[k * 64 + lane], point7<KIND>(above, below, jp, jm, ip, im, own[k], cf));
+    }
+  };
+  auto stage = [&](const double (&own)[8], double jm, double jp, double im, double ip, bool s_im, bool s_ip) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tile[k * kPlane + (hi + 1) * 8 + lo] = own[k];
+    tile[hi * kPlane + lo] = jm;
+    tile[hi * kPlane + 72 + lo] = jp;
+    if (!s_im) tile[hi * kPlane + 80 + lo] = im;
+    if (!s_ip) tile[hi * kPlane + 88 + lo] = ip;
+  };
+  if (fast) {
+    const uint32_t p0 = w > 0 ? entry(slot0 - 1) : BRK_LIST_SKIP, q0 = w + 1 < NW ? entry(slot0 + 1) : BRK_LIST_SKIP;
+    const uint32_t p1 = w > 0 ? entry(slot1 - 1) : BRK_LIST_SKIP, q1 = w + 1 < NW ? entry(slot1 + 1) : BRK_LIST_SKIP;
+    const bool s0m = p0 != BRK_LIST_SKIP && u(n0.im) == p0, s0p = q0 != BRK_LIST_SKIP && u(n0.ip) == q0;
+    const bool s1m = p1 != BRK_LIST_SKIP && u(n1.im) == p1, s1p = q1 != BRK_LIST_SKIP && u(n1.ip) == q1;
+    const double km0 = sbase(in + (size_t)u(n0.km) * step)[7 * 64 + lane];
+    const double jm0 = sbase(in + (size_t)u(n0.jm) * step)[hi * 64 + 7 * 8 + lo], jp0 = sbase(in + (size_t)u(n0.jp) * step)[hi * 64 + lo];
+    double im0 = 0.0, ip0 = 0.0, im1 = 0.0, ip1 = 0.0;
+    if (!s0m) im0 = sbase(in + (size_t)u(n0.im) * step)[hi * 64 + lo * 8 + 7];
+    if (!s0p) ip0 = sbase(in + (size_t)u(n0.ip) * step)[hi * 64 + lo * 8];
+    // brick 1's requests: in flight while brick 0 is staged, waited for at the barrier, and computed
+    const double kp1 = sbase(in + (size_t)u(n1.kp) * step)[lane];
+    const double jm1 = sbase(in + (size_t)u(n1.jm) * step)[hi * 64 + 7 * 8 + lo], jp1 = sbase(in + (size_t)u(n1.jp) * step)[hi * 64 + lo];
+    if (!s1m) im1 = sbase(in + (size_t)u(n1.im) * step)[hi * 64 + lo * 8 + 7];
+    if (!s1p) ip1 = sbase(in + (size_t)u(n1.ip) * step)[hi * 64 + lo * 8];
+    stage(own0, jm0, jp0, im0, ip0, s0m, s0p);
+    __syncthreads();
+    compute(b0, own0, km0, own1[0], s0m, s0p);
+    __syncthreads();
+    stage(own1, jm1, jp1, im1, ip1, s1m, s1p);
+    __syncthreads();
+    compute(b1, own1, own0[7], kp1, s1m, s1p);
+    return;
+  }
+  // ---- slow path: one brick at a time with private k-faces (any list)
+#pragma unroll 1
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t slot = q ? slot1 : slot0;
+    const uint32_t b = entry(slot);
+    const bool active = b != BRK_LIST_SKIP;
+    double own[8], km = 0.0, kp = 0.0;
+    bool s_im = false, s_ip = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) own[k] = 0.0;
+    if (active) {
+      const Nbr nb = load_nbr(adj, faces, b);
+      const uint32_t prev = w > 0 ? entry(slot - 1) : BRK_LIST_SKIP, next = w + 1 < NW ? entry(slot + 1) : BRK_LIST_SKIP;
+      s_im = prev != BRK_LIST_SKIP && u(nb.im) == prev;
+      s_ip = next != BRK_LIST_SKIP && u(nb.ip) == next;
+      const gcptr self = sbase(in + (size_t)b * step);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) own[k] = self[k * 64 + lane];
+      km = sbase(in + (size_t)u(nb.km) * step)[7 * 64 + lane];
+      kp = sbase(in + (size_t)u(nb.kp) * step)[lane];
+      const double jm = sbase(in + (size_t)u(nb.jm) * step)[hi * 64 + 7 * 8 + lo], jp = sbase(in + (size_t)u(nb.jp) * step)[hi * 64 + lo];
+      double im = 0.0, ip = 0.0;
+      if (!s_im) im = sbase(in + (size_t)u(nb.im) * step)[hi * 64 + lo * 8 + 7];
+      if (!s_ip) ip = sbase(in + (size_t)u(nb.ip) * step)[hi * 64 + lo * 8];
+      stage(own, jm, jp, im, ip, s_im, s_ip);
+    }
+    __syncthreads();
+    if (active) compute(b, own, km, kp, s_im, s_ip);
+    __syncthreads();
+  }
+}
+
+#endif // BRK_VARIANTS (two-bricks-per-wave experiments)
+
 } // namespace
 
 int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step,
@@ -510,7 +637,18 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
     else BRK_LAUNCH_WG_K(kCoeff, W);              \
   } while (0)
 #ifdef BRK_VARIANTS
-  if (variant == 7 || variant == 8 || variant == 9) { // two bricks per wave (two tiles): 7 = 4-wave groups at 3 per CU, 8 = 4-wave groups at 2 per CU, 9 = 8-wave groups
+  if (variant == 10 || variant == 11 || variant == 12) { // two k-consecutive bricks per wave, one tile: 10 = 8-wave groups at 24 waves/CU, 12 = at 16 waves/CU, 11 = 4-wave groups
+#define BRK_LAUNCH_KM(K)                                                                                                                             \
+  do {                                                                                                                                               \
+    if (variant == 10) hipLaunchKernelGGL((k_s7_km<K, 8, 6>), dim3((((n + 15) / 16 + 7) / 8) * 8), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces); \
+    else if (variant == 12) hipLaunchKernelGGL((k_s7_km<K, 8, 4>), dim3((((n + 15) / 16 + 7) / 8) * 8), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces); \
+    else hipLaunchKernelGGL((k_s7_km<K, 4, 6>), dim3((((n + 7) / 8 + 7) / 8) * 8), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces); \
+  } while (0)
+    if (kind == kMpi) BRK_LAUNCH_KM(kMpi);
+    else if (kind == kCond) BRK_LAUNCH_KM(kCond);
+    else BRK_LAUNCH_KM(kCoeff);
+#undef BRK_LAUNCH_KM
+  } else if (variant == 7 || variant == 8 || variant == 9) { // two bricks per wave (two tiles): 7 = 4-wave groups at 3 per CU, 8 = 4-wave groups at 2 per CU, 9 = 8-wave groups
 #define BRK_LAUNCH_2T(K)                                                                                                                              \
   do {                                                                                                                                                \
     if (variant == 7) hipLaunchKernelGGL((k_s7_2t<K, 4, 3>), dim3((((n + 7) / 8 + 7) / 8) * 8), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces); \

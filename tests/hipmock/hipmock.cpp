@@ -180,7 +180,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     return;
   }
   const bool s7 = name.find("k_s7_wg<") != std::string::npos, swg = name.find("k_star_wg<") != std::string::npos,
-             skp = name.find("k_star_kp<") != std::string::npos, cd = name.find("k_cube_dense<") != std::string::npos,
+             skp = name.find("k_star_kp<") != std::string::npos || name.find("k_star_km<") != std::string::npos, cd = name.find("k_cube_dense<") != std::string::npos,
              tp = name.find("k_taps<") != std::string::npos;
   if (s7 || swg || skp || cd || tp) {
     const uint32_t *adj = arg<const uint32_t *>(args, 0);
@@ -256,7 +256,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
       run_stencil(ta.at(0) == 0 ? BRK_27PT_COEFF : (ta.at(0) == 1 ? BRK_MPI125 : BRK_MPI7_X2), adj, in, out, step, list, cf);
       return;
     }
-    const std::vector<long> ta = targs(name, swg ? "k_star_wg" : "k_star_kp");
+    const std::vector<long> ta = targs(name, swg ? "k_star_wg" : (name.find("k_star_km<") != std::string::npos ? "k_star_km" : "k_star_kp"));
     check_faces(adj, arg<const uint32_t *>(args, 8), list);
     run_stencil(ta.at(0) == brk::kStarMpi13 ? BRK_MPI13 : BRK_MPI25, adj, in, out, step, list, cf);
     return;

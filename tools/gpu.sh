@@ -197,6 +197,20 @@ for k in ("single", "weak", "strong"):
     print(w or "alternating", k, round(d["value"], 1), d["unit"], "ms/step", round(d["ms_per_step"], 4), "frac", round(d["roofline"]["frac"], 4), extra)
 PY
   done ;;
+km7)     # 7-point: two k-consecutive bricks per wave with ONE tile (variant 10: 8-wave groups, 11: 4-wave groups; dev build) vs the default
+  run -n 512 -s 0 -S -o 8 -v 100 -i 60 -r2 3
+  run -n 512 -s 0 -S -o 8 -P -G 8 -v 110,112,100 -i 60 -r2 3
+  run -n 512 -s 0 -S -o 8 -P -G 4 -v 111,100 -i 60 -r2 3
+  run -n 512 -s 2 -S -o 8 -P -G 8 -v 110,100 -i 40 -r2 2
+  run -n 512 -s 0 -S -o 8 -v 110 -i 20 -r2 1 ;;
+kmarch)  # star kernels: NB k-consecutive bricks per wave (variant 4: NB = 4, 5: NB = 2; dev build) over k-stacked lists vs the defaults
+  for sid in 4 3; do
+    run -n 512 -s $sid -S -o 8 -v 100 -i 40 -r2 2
+    run -n 512 -s $sid -S -o 8 -P -v 103,105 -i 40 -r2 3
+    run -n 512 -s $sid -S -o 8 -P -K 4 -v 104 -i 40 -r2 3
+    run -n 512 -s $sid -S -o 4 -P -K 4 -v 104 -i 40 -r2 2
+    run -n 512 -s $sid -S -o 8 -v 104 -i 20 -r2 1     # the slow path (lists that are not k-stacked): correctness + cost
+  done ;;
 pair7)   # 7-point: two bricks per wave (variants 7 / 8 / 9, dev build) over k-paired and j-paired lists against the default kernel (list form, registered)
   run -n 512 -s 0 -S -o 8 -v 100 -i 60 -r2 3
   for ax in -P -J; do

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_stream2_persist(const double *in, doubl
 int main(int argc, char **argv) {
   int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1, rounds = 2;
   bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false, reg = false, kpair = false, jpair = false, zigzag = false;
-  long run = 4; // -P / -J: entries per run
+  long run = 4, nlev = 2; // -P / -J: entries per run; -P: k-levels per group (-K)
   std::vector<int> variants = {1, 2, 5};
   for (int a = 1; a < argc; ++a) {
     std::string o = argv[a];
@@ -178,6 +178,7 @@ int main(int argc, char **argv) {
     else if (o == "-P") kpair = true;      // with -o: k-paired order -- runs of 4 i-neighbours at k followed by the same run at k+1 (k_star_kp)
     else if (o == "-J") jpair = true;      // with -o: j-paired order -- runs of i-neighbours of row j followed by the same run of row j+1
     else if (o == "-G") run = atol(argv[++a]); // with -P / -J: entries per run (4 or 8)
+    else if (o == "-K") nlev = atol(argv[++a]); // with -P: k-levels per group (2 = pairs, 4 = the k-stacked order of k_star_km)
     else if (o == "-R") reg = true;        // brk_adjacency_register: the table is promised immutable
     else if (o == "-Z") zigzag = true;     // list form: every other launch walks each XCD's share of the list backwards (groups of 8 kept)
     else if (o == "-c") stream = true;     // also run the streaming-ceiling kernels
@@ -232,10 +233,10 @@ int main(int argc, char **argv) {
       if (kpair) {
         for (long x = 0; x < 8; ++x)
           for (long jb = 0; jb < rows; jb += order)
-            for (long k = 1; k < SB - 1; k += 2)
+            for (long k = 1; k < SB - 1; k += nlev)
               for (long j = x * rows + jb; j < x * rows + jb + order && j < (x + 1) * rows; ++j)
                 for (long ib = 1; ib < SB - 1; ib += run)
-                  for (long s2 = 0; s2 < 2; ++s2)
+                  for (long s2 = 0; s2 < nlev; ++s2)
                     for (long i = ib; i < ib + run; ++i) ids.push_back(k + s2 < SB - 1 && i < SB - 1 ? grid[((k + s2) * SB + (j + 1)) * SB + i] : BRK_LIST_SKIP);
       } else if (jpair) {
         for (long x = 0; x < 8; ++x)
