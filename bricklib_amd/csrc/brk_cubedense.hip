@@ -22,7 +22,7 @@
 // corner cells as pairs -- so that every 128-byte line is requested by one instruction of the wave.
 #include "brk_device.h"
 
-namespace brk {
+namespace brklib {
 #ifdef BRK_STAMP
 // diagnostic build only (make EXTRA_HIPFLAGS=-DBRK_STAMP): per-phase shader-clock totals of k_cube_dense, summed over waves
 constexpr unsigned kStampSlots = 1u << 19;
@@ -542,4 +542,4 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
   return BRK_OK;
 }
 
-} // namespace brk
+} // namespace brklib

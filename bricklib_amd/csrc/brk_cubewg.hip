@@ -9,7 +9,7 @@
 // Accumulation is the scatter form of cube_brick (each tile value is read once per (dj,di)).
 #include "brk_device.h"
 
-namespace brk {
+namespace brklib {
 namespace {
 
 template <int KIND, int NW>
@@ -162,4 +162,4 @@ int launch_cube_wg(int stencil_id, int nw, const uint32_t *adj, const double *in
   return BRK_OK;
 }
 
-} // namespace brk
+} // namespace brklib

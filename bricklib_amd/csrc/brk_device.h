@@ -8,7 +8,7 @@
 #include "brick-device.h"
 #include "brk_internal.h"
 
-namespace brk {
+namespace brklib {
 
 #ifdef BRK_DEV_KNOBS
 // development builds only (make DEV=1): unused dynamic LDS added to every stencil launch -> fewer workgroups resident per CU
@@ -62,5 +62,5 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
 int launch_cube_wg(int stencil_id, int nw, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 
-} // namespace brk
+} // namespace brklib
 #endif

@@ -19,7 +19,7 @@
 
 #include "brk_device.h"
 
-using namespace brk;
+using namespace brklib;
 
 namespace {
 
@@ -33,7 +33,7 @@ __device__ __forceinline__ uint32_t wave_slot(uint32_t n) {
 
 // ================================================================================================================
 // Generic kernels: one wave per brick, 4 waves per workgroup; the per-brick bodies live in include/brick-device.h
-// (shared with user kernels that call brk::brick_apply from a rewritten brick(...) line).  Earlier generation: compiled
+// (shared with user kernels that call brklib::brick_apply from a rewritten brick(...) line).  Earlier generation: compiled
 // only with -DBRK_VARIANTS (make VARIANTS=1), for A/B runs in tools/kbench and the variant parity tests.
 // ================================================================================================================
 #ifdef BRK_VARIANTS
@@ -324,12 +324,12 @@ int make_geom(const long dimlist[3], const long padding[3], const long ghost[3],
 
 #ifdef BRK_DEV_KNOBS
 // development builds only (make DEV=1 / VARIANTS=1 / EXTRA_HIPFLAGS=-DBRK_DIAG; tools/kbench): not part of the product ABI
-namespace brk {
+namespace brklib {
 size_t g_pad_lds = 0;
 int g_diag = 0;
 }
-extern "C" void brk_debug_pad_lds(size_t bytes) { brk::g_pad_lds = bytes; }
-extern "C" void brk_debug_diag(int d) { brk::g_diag = d; }
+extern "C" void brk_debug_pad_lds(size_t bytes) { brklib::g_pad_lds = bytes; }
+extern "C" void brk_debug_diag(int d) { brklib::g_diag = d; }
 
 extern "C" int brk_set_variant(int id, int v) {
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);

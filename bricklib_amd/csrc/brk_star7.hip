@@ -12,7 +12,7 @@
 // register prefetch pipeline, 16 vs 24 waves/CU, 16-B loads, k-stacked bricks carrying k-faces in registers.
 #include "brk_device.h"
 
-namespace brk {
+namespace brklib {
 namespace {
 
 constexpr int kPlane = 96; // doubles per k-plane of the tile: 10 rows x 8 + 8 (i-) + 8 (i+)
@@ -717,4 +717,4 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
   return BRK_OK;
 }
 
-} // namespace brk
+} // namespace brklib

@@ -8,7 +8,7 @@
 // k-neighbours stay in registers (a column of 8+2R values per lane).
 #include "brk_device.h"
 
-namespace brk {
+namespace brklib {
 namespace {
 
 template <int R>
@@ -702,4 +702,4 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
   return BRK_OK;
 }
 
-} // namespace brk
+} // namespace brklib

@@ -7,7 +7,7 @@ The reference describes a stencil in a small Python script (stencils/7pt.py, mpi
 and its code generator turns the expression into vector code (codegen/vecscatter, codegen/st/*).  Here the script is
 only *read*: it is executed against the recording stand-ins below for `st.expr` / `st.grid`, which reduce the expression
 to a list of taps (offset, coefficient expression).  Linear scripts then run through the generic kernel
-(brk_stencil_apply_taps / brk::brick_apply_taps) or -- when they are one of the built-in stencils -- through the tuned
+(brk_stencil_apply_taps / brklib::brick_apply_taps) or -- when they are one of the built-in stencils -- through the tuned
 kernels; anything non-linear (Func, If: cond.py) is reported as such.
 This module is written from the script syntax alone; it shares no code with the reference's `st` package."""
 import re

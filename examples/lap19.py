@@ -1,6 +1,6 @@
 # A user-written stencil in the reference's script syntax: a 19-point "face + edge" stencil with one coefficient per
 # shell (centre, 6 faces, 12 edges).  Not one of the built-in stencils: tools/brkscatter reads it as data and routes the
-# brick("lap19.py", ...) line to the generic tap path (brk::brick_apply_taps_static).
+# brick("lap19.py", ...) line to the generic tap path (brklib::brick_apply_taps_static).
 from st.expr import Index, ConstRef
 from st.grid import Grid
 

@@ -1,7 +1,7 @@
 // examples/single_hip.cpp -- the reference's single/hip driver shape (single/hip.cpp, stencils/3axis.hip.cpp:81-190)
 // on top of the MI355X engine, showing BOTH ways a driver reaches the kernels:
 //   (1) an unchanged `brick("7pt.py", VSVEC, (BDIM), (VFOLD), b)` line inside a __global__ kernel with one 64-thread
-//       block per brick (d3pt7_brick_trans of the reference), rewritten by tools/brkscatter into brk::brick_apply;
+//       block per brick (d3pt7_brick_trans of the reference), rewritten by tools/brkscatter into brklib::brick_apply;
 //   (2) one call of the C ABI, brk_stencil_apply_list, over the same `grid` entries (the fast path).
 // Both are checked with compareBrick against the array sweep on the CPU, like the reference does.
 //   build: make -C examples        run: examples/single_hip [N]
@@ -16,6 +16,7 @@
 #include "brickcompare.h"
 #include "bricksetup.h"
 #include "brk.h"
+#include "crash_trace.h"
 #include "multiarray.h"
 
 #ifndef N
@@ -77,6 +78,7 @@ __global__ void star37_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Br
 }
 
 int main() {
+  brk_crash::install(); // a crash prints its thread and call stack before the process dies by the signal (crash_trace.h)
   bElem *coeff = (bElem *)malloc(COEFF_SIZE * sizeof(bElem));
   {
     bElem *r = randomArray({COEFF_SIZE});

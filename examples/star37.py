@@ -1,7 +1,7 @@
 # A user-written stencil in the reference's script syntax: a radius-3 star (19 points) with different weights up- and
 # downwind -- coeff[d] at distance +d, coeff[3 + d] at distance -d on every axis, coeff[0] in the centre.  Not one of the
 # built-in stencils and beyond the 125-point cube: tools/brkscatter reads it as data and routes the brick("star37.py", ...) line to
-# the star-shaped tap path (brk::brick_apply_star_taps_static, radius up to 4).
+# the star-shaped tap path (brklib::brick_apply_star_taps_static, radius up to 4).
 from st.expr import Index, ConstRef
 from st.grid import Grid
 

@@ -27,6 +27,7 @@
 #include "brick-mpi.h"
 #include "bricktime.h"
 #include "brk.h"
+#include "crash_trace.h"
 
 #define BK(x)                                            \
   do {                                                   \
@@ -59,6 +60,7 @@ struct Rank {
 
 int main(int argc, char **argv) {
   setvbuf(stdout, nullptr, _IOLBF, 0); // the report survives whatever happens later, also into a pipe
+  brk_crash::install(); // a crash prints its thread and call stack before the process dies by the signal (crash_trace.h)
   const long d = argc > 1 ? atol(argv[1]) : 64, s = argc > 2 ? atol(argv[2]) : 16;
   const int size = argc > 3 ? atoi(argv[3]) : 3;
   const bool alias_local = !(argc > 4 && std::string(argv[4]) == "copy");

@@ -16,6 +16,7 @@
 #include "bricksetup.h"
 #include "bricktime.h"
 #include "brk.h"
+#include "crash_trace.h"
 
 int MPI_ITER = 20;
 
@@ -28,6 +29,7 @@ int MPI_ITER = 20;
   } while (0)
 
 int main(int argc, char **argv) {
+  brk_crash::install(); // a crash prints its thread and call stack before the process dies by the signal (crash_trace.h)
   const unsigned N = argc > 1 ? (unsigned)atoi(argv[1]) : 64;
   BrickDecomp<3, 8, 8, 8> bDecomp({N, N, N}, 8);
   bDecomp.initialize(skin3d_good);

@@ -14,7 +14,8 @@
 
 #include "brk.h"
 
-namespace brk {
+// (the namespace is not called `brk`: <unistd.h> declares the system call brk(), and the reference's weak/ and strong/ drivers include it)
+namespace brklib {
 
 // per-launch parameters every kernel receives by value: the stencil's coefficients and the direction of the sweep
 struct Coeffs {
@@ -922,5 +923,5 @@ __device__ __forceinline__ void brick_apply(const uint32_t *adj, const double *i
   }
 }
 
-} // namespace brk
+} // namespace brklib
 #endif // BRICK_DEVICE_H

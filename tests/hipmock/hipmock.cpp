@@ -94,7 +94,7 @@ std::vector<long> targs(const std::string &name, const char *kernel) {
   if (p == std::string::npos) return out;
   p += std::strlen(kernel) + 1;
   while (p < name.size() && name[p] != '>') {
-    while (p < name.size() && !(name[p] == '-' || (name[p] >= '0' && name[p] <= '9')) && name[p] != '>') ++p; // skips "(brk::Kind)"-style casts
+    while (p < name.size() && !(name[p] == '-' || (name[p] >= '0' && name[p] <= '9')) && name[p] != '>') ++p; // skips "(brklib::Kind)"-style casts
     if (name[p] == '>') break;
     out.push_back(std::strtol(name.c_str() + p, nullptr, 10));
     while (p < name.size() && name[p] != ',' && name[p] != '>') ++p;
@@ -124,7 +124,7 @@ std::vector<uint32_t> checked_list(const uint32_t *adj, const double *in, double
 
 void check_faces(const uint32_t *adj, const uint32_t *faces, const std::vector<uint32_t> &list) {
   if (!faces) return;
-  using brk::adj_slot;
+  using brklib::adj_slot;
   const int slots[6] = {adj_slot(-1, 0, 0), adj_slot(1, 0, 0), adj_slot(0, -1, 0), adj_slot(0, 1, 0), adj_slot(0, 0, -1), adj_slot(0, 0, 1)};
   for (uint32_t b : list) {
     need("compact face row", faces + (size_t)b * 8, 32);
@@ -141,11 +141,11 @@ struct BoxMirror {
   uint32_t base, ni_tot, nj_tot, lo[3], cnt[3];
 };
 
-void run_stencil(int id, const uint32_t *adj, const double *in, double *out, size_t step, const std::vector<uint32_t> &list, const brk::Coeffs &cf) {
+void run_stencil(int id, const uint32_t *adj, const double *in, double *out, size_t step, const std::vector<uint32_t> &list, const brklib::Coeffs &cf) {
   if (list.empty()) return;
   if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) { // the fused double sweep: 25 taps, weights in cf.c (make_coeffs)
     int off[75];
-    for (int t = 0; t < 25; ++t) off[3 * t] = brk::kDiamondTaps[t].di, off[3 * t + 1] = brk::kDiamondTaps[t].dj, off[3 * t + 2] = brk::kDiamondTaps[t].dk;
+    for (int t = 0; t < 25; ++t) off[3 * t] = brklib::kDiamondTaps[t].di, off[3 * t + 1] = brklib::kDiamondTaps[t].dj, off[3 * t + 2] = brklib::kDiamondTaps[t].dk;
     orc_brick_taps(adj, in, out, step, list.data(), (long)list.size(), 25, off, cf.c);
     return;
   }
@@ -169,7 +169,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     return;
   }
   if (name.find("k_star_taps<") != std::string::npos) { // (adj, in, out, step, ids, first, n, StarTaps)
-    const brk::StarTaps t = arg<brk::StarTaps>(args, 7);
+    const brklib::StarTaps t = arg<brklib::StarTaps>(args, 7);
     std::vector<int> off;
     for (int q = 0; q < t.n; ++q) off.insert(off.end(), {t.axis[q] == 0 ? t.off[q] : 0, t.axis[q] == 1 ? t.off[q] : 0, t.axis[q] == 2 ? t.off[q] : 0});
     const std::vector<uint32_t> list = checked_list(arg<const uint32_t *>(args, 0), arg<const double *>(args, 1), arg<double *>(args, 2), arg<size_t>(args, 3),
@@ -190,7 +190,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     const uint32_t *ids = arg<const uint32_t *>(args, 4);
     const uint32_t first = arg<uint32_t>(args, 5), n = arg<uint32_t>(args, 6);
     if (tp) {
-      const brk::Taps t = arg<brk::Taps>(args, 7);
+      const brklib::Taps t = arg<brklib::Taps>(args, 7);
       const std::vector<long> ta = targs(name, "k_taps");
       const int R = (int)ta.at(0);
       std::vector<int> off;
@@ -199,7 +199,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
         for (int dk = -R; dk <= R && !found; ++dk)
           for (int dj = -R; dj <= R && !found; ++dj)
             for (int di = -R; di <= R && !found; ++di)
-              if ((R == 1 ? brk::tap_rel<1>(di, dj, dk) : brk::tap_rel<2>(di, dj, dk)) == t.rel[q]) off.insert(off.end(), {di, dj, dk}), found = true;
+              if ((R == 1 ? brklib::tap_rel<1>(di, dj, dk) : brklib::tap_rel<2>(di, dj, dk)) == t.rel[q]) off.insert(off.end(), {di, dj, dk}), found = true;
         if (!found) abort();
       }
       const std::vector<uint32_t> list = checked_list(adj, in, out, step, ids, first, n);
@@ -210,7 +210,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
       const std::vector<long> ta = targs(name, "k_s7_wg"); // <kind, NW, MODE, DIAG>
       const int id = ta.at(0) == 1 ? BRK_MPI7 : (ta.at(0) == 2 ? BRK_COND7 : BRK_7PT_COEFF);
       const BoxMirror bx = arg<BoxMirror>(args, 7);
-      const brk::Coeffs cf = arg<brk::Coeffs>(args, 8);
+      const brklib::Coeffs cf = arg<brklib::Coeffs>(args, 8);
       const uint32_t *regmask = arg<const uint32_t *>(args, 9), *faces = arg<const uint32_t *>(args, 10);
       std::vector<uint32_t> list;
       if (ta.at(2) == 2) { // box mode: ids by arithmetic
@@ -230,7 +230,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
             const bool bit = (regmask[b >> 5] >> (b & 31)) & 1u;
             const uint32_t *row = adj + (size_t)b * 27;
             const uint32_t s1 = bx.ni_tot, s2 = bx.ni_tot * bx.nj_tot;
-            using brk::adj_slot;
+            using brklib::adj_slot;
             const bool regular = row[adj_slot(0, 0, -1)] == b - 1 && row[adj_slot(0, 0, 1)] == b + 1 && row[adj_slot(0, -1, 0)] == b - s1 &&
                                  row[adj_slot(0, 1, 0)] == b + s1 && row[adj_slot(-1, 0, 0)] == b - s2 && row[adj_slot(1, 0, 0)] == b + s2;
             if (bit && !regular) {
@@ -245,7 +245,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
       run_stencil(id, adj, in, out, step, list, cf);
       return;
     }
-    const brk::Coeffs cf = arg<brk::Coeffs>(args, 7);
+    const brklib::Coeffs cf = arg<brklib::Coeffs>(args, 7);
     const std::vector<uint32_t> list = checked_list(adj, in, out, step, ids, first, n);
     if (cd) {
       const std::vector<long> ta = targs(name, "k_cube_dense");
@@ -258,7 +258,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     }
     const std::vector<long> ta = targs(name, swg ? "k_star_wg" : (name.find("k_star_km<") != std::string::npos ? "k_star_km" : "k_star_kp"));
     check_faces(adj, arg<const uint32_t *>(args, 8), list);
-    run_stencil(ta.at(0) == brk::kStarMpi13 ? BRK_MPI13 : BRK_MPI25, adj, in, out, step, list, cf);
+    run_stencil(ta.at(0) == brklib::kStarMpi13 ? BRK_MPI13 : BRK_MPI25, adj, in, out, step, list, cf);
     return;
   }
   if (name.find("k_face_table") != std::string::npos) {
@@ -267,7 +267,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     uint32_t *faces = arg<uint32_t *>(args, 2);
     need("adjacency table", adj, (size_t)nb * 27 * 4);
     need("face table", faces, (size_t)nb * 32);
-    using brk::adj_slot;
+    using brklib::adj_slot;
     for (uint32_t b = 0; b < nb; ++b) {
       const uint32_t *row = adj + (size_t)b * 27;
       const uint32_t v[8] = {row[adj_slot(-1, 0, 0)], row[adj_slot(1, 0, 0)], row[adj_slot(0, -1, 0)], row[adj_slot(0, 1, 0)],
@@ -283,7 +283,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     const uint32_t s1 = reg ? arg<uint32_t>(args, 2) : 0, s2 = reg ? arg<uint32_t>(args, 3) : 0;
     uint32_t *mask = arg<uint32_t *>(args, reg ? 4 : 2);
     need("adjacency table", adj, (size_t)nb * 27 * 4);
-    using brk::adj_slot;
+    using brklib::adj_slot;
     // what the launch writes: per wave of 64 threads two (regular) or four (link) words, also for the waves past nbricks
     const uint32_t threads = grid.x * block.x;
     need("mask", mask, (size_t)(threads / 64) * (reg ? 8 : 16));

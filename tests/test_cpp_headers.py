@@ -99,6 +99,22 @@ REF = "/root/reference"
 REF_EXE = os.path.join(ROOT, "examples", "_ref", "single_hip_ref")
 
 
+def test_headers_coexist_with_unistd(tmp_path):
+    """The reference's weak/ and strong/ drivers include <unistd.h> (weak/main.cu:21, strong/main.cu:21), which declares the system
+    call brk(): no name of the device-side headers may collide with it (round 4: the helper namespace was called `brk`)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = tmp_path / "t.cpp"
+    src.write_text('#include <unistd.h>\n#include <signal.h>\n#include "brick-hip.h"\n#include "brick-mpi.h"\n#include "brick-device.h"\n'
+                   '__global__ void k(const unsigned *adj, const double *in, double *out, unsigned b) { brklib::brick_apply<BRK_MPI7>(adj, in, out, 512, b, nullptr); }\n'
+                   'int main() { return (int)(getpid() & 0); }\n')
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-x", "hip", "-DBRK_NO_MPI", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                        "-o", str(tmp_path / "t.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "stencils")), reason="needs the reference tree (build container only)")
 def test_reference_single_hip_builds_unchanged():
     """The reference's OWN single/hip driver -- single/hip.cpp + stencils/3axis.hip.cpp, read from where they lie, zero source

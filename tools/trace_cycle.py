@@ -4,7 +4,7 @@ rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-short = lambda n: re.sub(r"\(anonymous namespace\)::|void |brk::", "", n).split("(")[0][:28]
+short = lambda n: re.sub(r"\(anonymous namespace\)::|void |brklib::", "", n).split("(")[0][:28]
 ks = [(short(r["Kernel_Name"]), int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Grid_Size_X"])) for r in rows]
 idx = [i for i, k in enumerate(ks) if "link_copy" in k[0]]
 lo, hi = idx[-7], idx[-6]          # the bench appends 5 exchange-only launches after the timed loop
