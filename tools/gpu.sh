@@ -57,6 +57,9 @@ PY
   cp $(ls -t $(find gpurun_out/prof_kt -name "*kernel_stats.csv") | head -1) $d/kernel_stats.csv
   bash tools/prof_pmc.sh $tag > $d/pmc.log 2>&1; tail -40 $d/pmc.log
   cp gpurun_out/pmc_$tag/summary.txt $d/pmc_summary.txt; cp gpurun_out/pmc_$tag/traffic.json $d/pmc_traffic_all.json
+  # the same passes with successive sweeps in alternating directions: does any memory-side counter see the Infinity-Cache re-reads?
+  bash tools/prof_pmc.sh ${tag}_alt --alternate --no-config3 > $d/pmc_alt.log 2>&1; tail -12 $d/pmc_alt.log
+  cp gpurun_out/pmc_${tag}_alt/summary.txt $d/pmc_summary_alternating.txt; cp gpurun_out/pmc_${tag}_alt/traffic.json $d/pmc_traffic_alternating.json
   grep '^{' gpurun_out/prof_kt.log | tail -1 > $d/bench_under_rocprof.json
   python3 - $d <<'PY'
 import json, csv, sys

@@ -14,6 +14,10 @@ BENCH_ARGS="$*"
 run p1 FETCH_SIZE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
 run p2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE
 run p3 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM
+# round 4: the only memory-side counters this profiler lists that name DRAM -- L2 requests "destined for DRAM (MC)".  They sit on the
+# L2 side of the fabric like RDREQ / WRREQ, i.e. IN FRONT of the Infinity Cache: compare a one-way run with `--alternate` to see
+# whether they can tell Infinity-Cache hits from HBM reads (profiles/README.md, round 4)
+run p4 TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 python3 - "$tag" <<'PY'
 import csv, glob, sys, collections, re
 tag=sys.argv[1]
