@@ -678,6 +678,16 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
   // chains, 168 VGPRs with spills for the radius-4 star).  Lists that are NOT paired go through the march kernel's slow path (one
   // brick at a time: 0.565 / 0.445 ms) -- declare only what is true.  -DBRK_VARIANTS builds: variant 3 = k_star_kp.
 #ifdef BRK_VARIANTS
+  if (variant == 4 || variant == 5) { // experiments: 4 = four k-consecutive bricks per wave (k-stacked lists), 5 = the 13-point march at 5 waves per SIMD
+    const uint32_t per = variant == 4 ? 16 : 8;
+    const uint32_t wgsm = (((n + per - 1) / per + 7) / 8) * 8;
+    if (stencil_id == BRK_MPI13 && variant == 4) hipLaunchKernelGGL((k_star_km<kStarMpi13, 4, 4>), dim3(wgsm), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
+    else if (stencil_id == BRK_MPI13) hipLaunchKernelGGL((k_star_km<kStarMpi13, 2, 5>), dim3(wgsm), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
+    else if (variant == 4) hipLaunchKernelGGL((k_star_km<kStarMpi25, 4, 3>), dim3(wgsm), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
+    else hipLaunchKernelGGL((k_star_km<kStarMpi25, 2, 4>), dim3(wgsm), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
+    HIP_TRY(hipGetLastError());
+    return BRK_OK;
+  }
   if (variant == 3) {
     const uint32_t wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
     if (stencil_id == BRK_MPI13) hipLaunchKernelGGL((k_star_kp<kStarMpi13, 4>), dim3(wgs8), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);

@@ -200,6 +200,9 @@ for k in ("single", "weak", "strong"):
     print(w or "alternating", k, round(d["value"], 1), d["unit"], "ms/step", round(d["ms_per_step"], 4), "frac", round(d["roofline"]["frac"], 4), extra)
 PY
   done ;;
+km13)    # 13-point march at 5 waves per SIMD (variant 5, dev build) against the default march (variant 0 over a k-paired list: kbench declares nothing, so the tiled kernel answers -- use bench for the default)
+  run -n 512 -s 3 -S -o 8 -P -v 105,103,100 -i 60 -r2 3
+  run -n 512 -s 4 -S -o 8 -P -v 105,103 -i 40 -r2 2 ;;
 km7)     # 7-point: two k-consecutive bricks per wave with ONE tile (variant 10: 8-wave groups, 11: 4-wave groups; dev build) vs the default
   run -n 512 -s 0 -S -o 8 -v 100 -i 60 -r2 3
   run -n 512 -s 0 -S -o 8 -P -G 8 -v 110,112,100 -i 60 -r2 3
