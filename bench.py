@@ -422,7 +422,9 @@ def run_single(args, bl, dev):
                  "successive sweeps in alternating directions (--alternate makes this the headline): a sweep starts in the part of the never-rewritten "
                  "input the Infinity Cache still holds, so this fraction is algorithmic bytes / time / 8 TB/s with part of the reads NOT served by HBM; "
                  "the headline (one direction) is the HBM number")}
-    res = {"workload": f"single-{name}-{N}" + (f"-variant{args.variant}" if args.variant else ""), "layout": args.layout, "form": args.form, "sweep_direction": "alternating" if zigzag else "one way", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+    res = {"workload": f"single-{name}-{N}" + (f"-variant{args.variant}" if args.variant else ""), "layout": args.layout, "form": args.form,
+           # what BrickStorage.allocate measured when it placed the output storage against the input storage (brk_storage_alloc, include/brk.h)
+           "storage_placement": sto.placement, "sweep_direction": "alternating" if zigzag else "one way", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
            "kernel": "%s over %d bricks" % ("k_s7_wg<8 waves>" if name in ("7pt", "mpi7pt") else ("k_star_wg" if name in ("mpi13pt", "mpi25pt") else "k_cube_dense"), ids.size)}
     extra["timing"] = {"protocol": "%s%d warm-up steps, then the median of %d windows of %d launches, each between two device synchronisations"
@@ -1032,7 +1034,7 @@ def main():
                        **{k: res[k] for k in ("layout", "form", "sweep_direction", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift", "transport", "transport_fallback_reason", "exchange_self_check", "messages_per_exchange",
                                              "per_peer_send_bytes", "per_peer_GBps_exchange_alone", "distinct_gpus", "ranks_seen", "phases", "rccl_library",
-                                             "local_ghosts", "local_link_bytes_per_rank", "swept_bricks_per_sweep", "subdomain_bricks") if k in res}},
+                                             "local_ghosts", "local_link_bytes_per_rank", "swept_bricks_per_sweep", "subdomain_bricks", "storage_placement") if k in res}},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "frac_by_step": ach_step / HBM_PEAK_GBS,
                          "frac_of_measured_copy": ach / HBM_COPY_GBS, "traffic": None, "kernel": res["kernel"],

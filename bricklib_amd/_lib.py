@@ -21,6 +21,11 @@ class Region(C.Structure):
                 ("len", C.c_uint32), ("first_pad", C.c_uint32), ("last_pad", C.c_uint32)]
 
 
+class Placement(C.Structure):
+    """brk_placement: what brk_storage_alloc measured while it placed a storage"""
+    _fields_ = [("candidates", C.c_int), ("chosen", C.c_int), ("ms_per_gib_chosen", C.c_double), ("ms_per_gib_worst", C.c_double)]
+
+
 class Link(C.Structure):
     """brk_link"""
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("bytes", C.c_uint64)]
@@ -51,6 +56,9 @@ def _load():
     if hasattr(L, "brk_set_variant"):      # development builds only (make DEV=1 / VARIANTS=1): not part of the product ABI
         L.brk_set_variant.argtypes = [C.c_int, C.c_int]
     L.brk_link_copy.argtypes = [vp, C.c_uint32, C.c_uint64, vp]
+    L.brk_storage_alloc.argtypes = [C.c_size_t, C.POINTER(vp), C.POINTER(Placement)]
+    L.brk_storage_free.argtypes = [vp]
+    L.brk_placement_probe.argtypes = [vp, vp, C.c_size_t, vp, f64p]
     L.brk_array_to_brick.argtypes = [L3, L3, L3, vp, vp, vp, C.c_size_t, vp]
     L.brk_brick_to_array.argtypes = [L3, L3, L3, vp, vp, vp, C.c_size_t, vp]
     L.brk_compare_brick.argtypes = [L3, L3, L3, vp, vp, vp, C.c_size_t, C.c_double, vp, vp]
@@ -152,6 +160,7 @@ ABI_SYMBOLS = [
     "brk_exchange_begin", "brk_exchange_transport", "brk_exchange_end", "brk_exchange_run", "brk_exchange_loopback",
     "brk_exchange_view_buffer", "brk_exchange", "brk_comm_unique_id", "brk_comm_init_rank", "brk_comm_destroy", "brk_comm_rank", "brk_comm_library",
     "brk_adjacency_register", "brk_adjacency_release", "brk_decomp_build_order", "brk_skin3d_order",
+    "brk_storage_alloc", "brk_storage_free", "brk_placement_probe",
 ]
 
 

@@ -5,7 +5,9 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import check, l3, lib
+import os
+
+from ._lib import Placement, check, l3, lib
 
 BRICK_TOLERANCE = 1e-6  # include/cmpconst.h:9
 BDIM = (8, 8, 8)
@@ -76,15 +78,58 @@ class BrickInfo:
         return BrickStorage.allocate(self.nbricks, step, device)
 
 
-class BrickStorage:
-    """Flat storage of `chunks` chunks of `step` elements (include/brick.h:53-82)."""
+class _PlacedMemory:
+    """Device memory from brk_storage_alloc, handed to torch through __cuda_array_interface__ (torch keeps this object alive for
+    as long as a tensor aliases the memory) and given back with brk_storage_free when the last tensor is gone."""
 
-    def __init__(self, dat, chunks, step):
-        self.dat, self.chunks, self.step = dat, int(chunks), int(step)
+    def __init__(self, nelem, device):
+        self.device, self.nelem = device, int(nelem)
+        ptr, rep = C.c_void_p(), Placement()
+        with torch.cuda.device(device):
+            check(lib.brk_storage_alloc(self.nelem * 8, C.byref(ptr), C.byref(rep)))
+        self.ptr = ptr.value
+        self.report = {"candidates": rep.candidates, "chosen": rep.chosen, "ms_per_gib_chosen": rep.ms_per_gib_chosen,
+                       "ms_per_gib_worst": rep.ms_per_gib_worst}
+        self.__cuda_array_interface__ = {"shape": (self.nelem,), "typestr": "<f8", "data": (self.ptr, False), "version": 2}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            try:
+                with torch.cuda.device(self.device):
+                    lib.brk_storage_free(C.c_void_p(ptr))
+            except Exception:
+                pass
+
+
+PLACE_MIN_BYTES = 64 << 20     # brk_storage_alloc measures storages from this size on (include/brk.h)
+
+
+class BrickStorage:
+    """Flat storage of `chunks` chunks of `step` elements (include/brick.h:53-82).
+
+    Device storages of 64 MiB and more are PLACED (brk_storage_alloc, include/brk.h): HBM consists of regions of about 8 GiB, and
+    a sweep between two storages in regions of the same kind runs 2.7 % slower than between regions of different kinds, so the
+    allocation is a measured one -- see bricklib_amd/csrc/brk_place.hip.  `placement` holds what was measured (None for small,
+    host or BRK_PLACEMENT=0 storages, which come from torch's allocator as before)."""
+
+    def __init__(self, dat, chunks, step, placement=None):
+        self.dat, self.chunks, self.step, self.placement = dat, int(chunks), int(step), placement
 
     @staticmethod
     def allocate(chunks, step, device="cuda"):
-        return BrickStorage(torch.zeros(int(chunks) * int(step), dtype=torch.float64, device=device), chunks, step)
+        n = int(chunks) * int(step)
+        dev = torch.device(device)
+        if dev.type == "cuda" and n * 8 >= PLACE_MIN_BYTES and os.environ.get("BRK_PLACEMENT", "1") != "0":
+            if dev.index is None:
+                dev = torch.device("cuda", torch.cuda.current_device())
+            mem = _PlacedMemory(n, dev)
+            dat = torch.as_tensor(mem, device=dev)
+            if dat.data_ptr() != mem.ptr or dat.dtype != torch.float64 or dat.numel() != n:
+                raise RuntimeError("BrickStorage.allocate: torch did not alias the placed storage")
+            dat.zero_()
+            return BrickStorage(dat, chunks, step, mem.report)
+        return BrickStorage(torch.zeros(n, dtype=torch.float64, device=device), chunks, step)
 
 
 class Brick:

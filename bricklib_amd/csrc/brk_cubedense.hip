@@ -183,7 +183,8 @@ __device__ __forceinline__ bool linked(uint32_t rl, uint32_t rr, int lane) {
 template <int KIND, int NW, int OCC, int PIPE = 1>
 __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
-    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf, int diag, const uint32_t *__restrict__ linkmask) {
+    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf, int diag, const uint32_t *__restrict__ linkmask,
+    const uint32_t *__restrict__ cubemask, uint32_t cs1, uint32_t cs2) {
   constexpr int R = CubeTraits<KIND>::R;
   using TL = DenseTile<KIND>;
   using X = DX<KIND>;
@@ -253,7 +254,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
     // the three adjacency rows are requested BEFORE the brick itself: vector loads return in order, and everything
     // below (links, face addresses) waits for the rows -- behind the 4 KiB of the brick that wait is a full HBM round trip
     // (in-kernel stamps: 8500 of a wave's 15000 cycles went by before the face loads were issued)
-    const uint32_t arow = adj[(size_t)b * 27 + l27]; // lanes 0..26: the adjacency row
+    // lanes 0..26: the adjacency row.  Box entry point over a registered table: a brick whose 26 neighbours are the ids the box
+    // numbering predicts (one bit per brick, k_regular_mask in its cube form; a scalar load) computes its row -- the vector load of
+    // the row is the one dependent round trip through the saturated vector memory path in front of a wave's own requests
+    uint32_t arow;
+    const bool predicted = cubemask && ((cubemask[b >> 5] >> (b & 31u)) & 1u);
+    if (predicted) arow = b + (uint32_t)(l27 / 9 - 1) * cs2 + (uint32_t)((l27 / 3) % 3 - 1) * cs1 + (uint32_t)(l27 % 3 - 1);
+    else arow = adj[(size_t)b * 27 + l27];
     // registered adjacency table (brk_adjacency_register): two bits per brick say whether it is linked to its -i / +i adjacency
     // neighbour (k_link_mask, brk_kernels.hip), so the rows of the list neighbours are not read -- measured with them ablated
     // (profiles/r03_b_cube_kernel_ablations.txt): 3.7 % (27-point) and 4.4 % (125-point) of the sweep
@@ -511,11 +518,16 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 // static accumulators and one read burst per plane, 9 = the same with the rolled loop over a ring, 6 = NW 4 and 7 = NW 8 with the
 // software-pipelined rolled loop (2 waves/SIMD)
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *linkmask) {
+                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *linkmask, const CubeRegular &cubereg_in) {
+#ifdef BRK_DEV_KNOBS
+  const CubeRegular cubereg = (g_diag & 256) ? CubeRegular() : cubereg_in; // development bit 256: every adjacency row is loaded (A/B of the predicted rows)
+#else
+  const CubeRegular &cubereg = cubereg_in;
+#endif
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8;
   const bool x2 = stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2;
 #define BRK_CD(KIND, NW, OCC, PIPE, WGS, LDS) \
-  hipLaunchKernelGGL((k_cube_dense<KIND, NW, OCC, PIPE>), dim3(WGS), dim3(64 * NW), LDS, st, adj, in, out, step, ids, first, n, cf, g_diag, linkmask)
+  hipLaunchKernelGGL((k_cube_dense<KIND, NW, OCC, PIPE>), dim3(WGS), dim3(64 * NW), LDS, st, adj, in, out, step, ids, first, n, cf, g_diag, linkmask, cubereg.mask, cubereg.s1, cubereg.s2)
 #ifdef BRK_VARIANTS
   const uint32_t wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
   bool done = true;

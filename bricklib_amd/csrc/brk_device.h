@@ -57,8 +57,14 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
 
 // 27-/125-point kernels: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip), and the earlier padded
 // tiles with shared i-halos (brk_cubewg.hip)
+// `cubereg`: the box entry point over a registered table -- one bit per brick "all 26 neighbours are the ids the lexicographic
+// numbering with strides (s1, s2) predicts" (k_regular_mask, cube form): such a brick's adjacency row is computed, not loaded
+struct CubeRegular {
+  const uint32_t *mask = nullptr;
+  uint32_t s1 = 0, s2 = 0;
+};
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *linkmask);
+                      uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *linkmask, const CubeRegular &cubereg = CubeRegular());
 int launch_cube_wg(int stencil_id, int nw, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 

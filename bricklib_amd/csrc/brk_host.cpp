@@ -25,7 +25,7 @@ int brk_fail(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *brk_last_error(void) { return g_err; }
-extern "C" int brk_abi_version(void) { return 1006; } // 1001: brk_stencil_apply_taps; 1002: BRK_MPI7_X2, BRK_7PT_X2; 1003: exchange; 1004: brk_adjacency_register; 1005: brk_stencil_apply_*_ex; 1006: brk_comm_library, brk_set_variant left the ABI
+extern "C" int brk_abi_version(void) { return 1007; } // 1001: brk_stencil_apply_taps; 1002: BRK_MPI7_X2, BRK_7PT_X2; 1003: exchange; 1004: brk_adjacency_register; 1005: brk_stencil_apply_*_ex; 1006: brk_comm_library, brk_set_variant left the ABI; 1007: brk_storage_alloc / _free, brk_placement_probe
 
 // ---------------------------------------------------------------------------------------------- stencil facts
 extern "C" int brk_stencil_radius(int id) {

@@ -234,9 +234,13 @@ std::mutex g_adj_mutex;
 int link_mask_locked(const uint32_t *adj, const uint32_t **out);
 // ... and the six face neighbours of every brick as one aligned 32-byte row (see k_face_table)
 int face_table_locked(const uint32_t *adj, const uint32_t **out);
+// ... and, per pair of id strides, one bit per brick "the neighbours are the ids a lexicographic numbering with these strides predicts"
+int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, int cube, hipStream_t st, const uint32_t **out);
 
+// box_strides: the launch comes from the box entry point -- ids are base + (k * tot[1] + j) * tot[0] + i, strides {tot[0], tot[0] * tot[1]}
 int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
-                   uint32_t first, uint32_t n, const double *coeff_host, brk_stream s, bool kpaired = false, bool reverse = false) {
+                   uint32_t first, uint32_t n, const double *coeff_host, brk_stream s, bool kpaired = false, bool reverse = false,
+                   const uint32_t *box_strides = nullptr) {
   if (id < 0 || id >= BRK_NSTENCIL) return brk_fail(BRK_EINVAL, "unknown stencil id %d", id);
   if (!adj || !in || !out) return brk_fail(BRK_EINVAL, "null device pointer");
   if (in == out) return brk_fail(BRK_EINVAL, "in and out must be different fields");
@@ -254,9 +258,16 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   cf.reverse = reverse ? 1u : 0u;
   hipStream_t st = static_cast<hipStream_t>(s);
   const uint32_t *lmask = nullptr, *faces = nullptr;
+  CubeRegular cubereg;
   std::lock_guard<std::mutex> adj_lock(g_adj_mutex); // held until the launch below is enqueued (see the lifetime rule above)
   if (id == BRK_27PT_COEFF || id == BRK_MPI125 || id == BRK_MPI7_X2 || id == BRK_7PT_X2) {
     if (int rc = link_mask_locked(adj, &lmask)) return rc; // cube kernels over a registered table: the rows of the list neighbours need not be read
+    // measured (profiles/r04_h_predicted_rows.txt, interleaved): 27-point -0.8 ... -1.5 %, fused double 7-point pass -1 %, 125-point +1.7 %
+    // (its waves then issue their requests earlier and collide more): the 125-point kernel keeps loading its rows
+    if (box_strides && lmask && id != BRK_MPI125) {
+      cubereg.s1 = box_strides[0], cubereg.s2 = box_strides[1];
+      if (int rc = regular_mask_locked(adj, cubereg.s1, cubereg.s2, 1, st, &cubereg.mask)) return rc;
+    }
   } else {
     if (int rc = face_table_locked(adj, &faces)) return rc; // star kernels over a registered table: one 32-byte row of face ids instead of a 108-byte row
   }
@@ -266,10 +277,10 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   if ((id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) && var != 1)
     return launch_star7(id, var == 0 ? kDefaultStar7Variant : var, adj, in, out, step, ids, first, n, cf, st, faces);
   if ((id == BRK_MPI13 || id == BRK_MPI25) && var != 1) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st, faces, kpaired);
-  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st, lmask);
+  if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st, lmask, cubereg);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = var;
-    if (v == 0 || (v >= 5 && v <= 14)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st, lmask);
+    if (v == 0 || (v >= 5 && v <= 14)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st, lmask, cubereg);
     if ((id == BRK_27PT_COEFF && v == 2) || (id == BRK_MPI125 && (v == 2 || v == 4 || v == 8)))
       return launch_cube_wg(id, id == BRK_MPI125 ? v : 8, adj, in, out, step, ids, first, n, cf, st);
   }
@@ -294,7 +305,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
 #else
   if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) return launch_star7(id, kDefaultStar7Variant, adj, in, out, step, ids, first, n, cf, st, faces);
   if (id == BRK_MPI13 || id == BRK_MPI25) return launch_star_wg(id, var, adj, in, out, step, ids, first, n, cf, st, faces, kpaired);
-  return launch_cube_dense(id, 0, adj, in, out, step, ids, first, n, cf, st, lmask);
+  return launch_cube_dense(id, 0, adj, in, out, step, ids, first, n, cf, st, lmask, cubereg);
 #endif
 }
 
@@ -464,7 +475,8 @@ int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], 
 // six face neighbours are b -+ 1, b -+ s1, b -+ s2 -- what the lexicographic numbering of a box predicts -- which lets the 7-point
 // box kernel skip the adjacency rows of those bricks.  Unregistered tables work exactly as before.
 namespace {
-__global__ void k_regular_mask(const uint32_t *__restrict__ adj, uint32_t nbricks, uint32_t s1, uint32_t s2, uint32_t *__restrict__ mask) {
+// cube != 0: all 26 neighbours (and the brick's own entry) are the predicted ones -- the cube kernels' form of the same promise
+__global__ void k_regular_mask(const uint32_t *__restrict__ adj, uint32_t nbricks, uint32_t s1, uint32_t s2, uint32_t *__restrict__ mask, int cube) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
   if (b < nbricks) {
@@ -472,6 +484,10 @@ __global__ void k_regular_mask(const uint32_t *__restrict__ adj, uint32_t nbrick
     ok = row[adj_slot(0, 0, -1)] == b - 1 && row[adj_slot(0, 0, 1)] == b + 1 && row[adj_slot(0, -1, 0)] == b - s1 &&
          row[adj_slot(0, 1, 0)] == b + s1 && row[adj_slot(-1, 0, 0)] == b - s2 && row[adj_slot(1, 0, 0)] == b + s2 &&
          b >= s2 && b + s2 < nbricks; // the predicted ids exist
+    if (cube) {
+      ok = ok && b >= s2 + s1 + 1 && (uint64_t)b + s2 + s1 + 1 < nbricks;
+      for (int q = 0; q < 27 && ok; ++q) ok = row[q] == b + (uint32_t)(q / 9 - 1) * s2 + (uint32_t)((q / 3) % 3 - 1) * s1 + (uint32_t)(q % 3 - 1);
+    }
   }
   const unsigned long long m = __ballot(ok);
   if ((threadIdx.x & 63) == 0) {
@@ -525,6 +541,7 @@ struct AdjEntry {
   int device;
   struct Mask {
     uint32_t s1, s2;
+    int cube; // 0: the six face neighbours are the predicted ones (7-point box kernel); 1: all 26 (cube kernels)
     uint32_t *dev;
     uint64_t stamp;
   };
@@ -560,12 +577,12 @@ int same_device(const AdjEntry &e) {
 // the face-regularity mask of a registered table for id strides (s1, s2), built on first use of that pair (that one call is
 // synchronous on `st`: the strides are a property of the launch, not of the table); nullptr (and BRK_OK) when the table is not
 // registered.  Caller holds g_adj_mutex.
-int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, hipStream_t st, const uint32_t **out) {
+int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, int cube, hipStream_t st, const uint32_t **out) {
   *out = nullptr;
   AdjEntry *e = find_locked(adj);
   if (!e) return BRK_OK;
   for (auto &m : e->masks)
-    if (m.s1 == s1 && m.s2 == s2) {
+    if (m.s1 == s1 && m.s2 == s2 && m.cube == cube) {
       m.stamp = ++g_mask_clock;
       *out = m.dev;
       return BRK_OK;
@@ -574,7 +591,7 @@ int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, hipStream
   const uint32_t words = 2 * ((e->nbricks + 255) / 256 * 4);
   uint32_t *mask = nullptr;
   HIP_TRY(hipMalloc(&mask, (size_t)words * sizeof(uint32_t)));
-  hipLaunchKernelGGL(k_regular_mask, dim3((e->nbricks + 255) / 256), dim3(256), 0, st, adj, e->nbricks, s1, s2, mask);
+  hipLaunchKernelGGL(k_regular_mask, dim3((e->nbricks + 255) / 256), dim3(256), 0, st, adj, e->nbricks, s1, s2, mask, cube);
   hipError_t r = hipGetLastError();
   if (r == hipSuccess) r = hipStreamSynchronize(st);
   if (r != hipSuccess) {
@@ -588,7 +605,7 @@ int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, hipStream
     (void)hipFree(e->masks[victim].dev);
     e->masks.erase(e->masks.begin() + victim);
   }
-  e->masks.push_back({s1, s2, mask, ++g_mask_clock});
+  e->masks.push_back({s1, s2, cube, mask, ++g_mask_clock});
   *out = mask;
   return BRK_OK;
 }
@@ -754,7 +771,7 @@ extern "C" int brk_stencil_apply_box_ex(int id, const uint32_t *adj, const doubl
   if (id == BRK_7PT_COEFF || id == BRK_MPI7 || id == BRK_COND7) {
     const uint32_t *regmask = nullptr, *faces = nullptr; // registered adjacency: bricks whose face neighbours are the predicted ones skip their rows
     std::lock_guard<std::mutex> adj_lock(g_adj_mutex);   // until the launch is enqueued
-    if (int rc = regular_mask_locked(adj, tot[0], tot[0] * tot[1], static_cast<hipStream_t>(s), &regmask)) return rc;
+    if (int rc = regular_mask_locked(adj, tot[0], tot[0] * tot[1], 0, static_cast<hipStream_t>(s), &regmask)) return rc;
     if (int rc = face_table_locked(adj, &faces)) return rc;
     return launch_star7_box(id, adj, in, out, step, base, tot, lo, cnt, cf, static_cast<hipStream_t>(s), regmask, faces);
   }
@@ -767,7 +784,8 @@ extern "C" int brk_stencil_apply_box_ex(int id, const uint32_t *adj, const doubl
   // Infinity Cache and are not what bounds the kernel, the shorter rows-in-flight window is (profiles/r03_d_25pt_rows_per_block.txt).
   const bool kpair = id == BRK_MPI25 || id == BRK_MPI13; // the stars march two k-consecutive bricks per wave over k-paired lists (k_star_km, brk_starwg.hip)
   if (int rc = box_list_locked(base, tot, lo, cnt, 8u, kpair, &e)) return rc;
-  if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s, kpair, reverse)) return rc;
+  const uint32_t strides[2] = {tot[0], tot[0] * tot[1]};
+  if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s, kpair, reverse, strides)) return rc;
   HIP_TRY(hipEventRecord(e->last_use, static_cast<hipStream_t>(s)));
   return BRK_OK;
 }

@@ -86,7 +86,9 @@ int main(int argc, char **argv) {
     R.l = lr[0], R.r = lr[1], R.nsub = (size_t)(lr[1] - lr[0]);
     const size_t elems = R.nsub * nb * 512;
     for (int w = 0; w < 3; ++w) {
-      gpuCheck(hipMalloc(&R.st[w], elems * esz));
+      void *placed = nullptr; // placed in HBM against the storages allocated before it (brk.h: brk_storage_alloc)
+      BK(brk_storage_alloc(elems * esz, &placed, nullptr));
+      R.st[w] = static_cast<double *>(placed);
       gpuCheck(hipMemset(R.st[w], 0, elems * esz));
     }
     // fill: subdomain with Z-Morton id z sits at block coordinates (zmort(z,0), zmort(z,1), zmort(z,2)) * s
@@ -252,7 +254,7 @@ int main(int argc, char **argv) {
   for (auto &R : ranks) {
     brk_exchange_view_free(R.view);
     brk_xplan_free(R.plan);
-    for (int w = 0; w < 3; ++w) gpuCheck(hipFree(R.st[w]));
+    for (int w = 0; w < 3; ++w) BK(brk_storage_free(R.st[w]));
     gpuCheck(hipFree(R.adj));
     gpuCheck(hipFree(R.list_all));
     gpuCheck(hipFree(R.list_domain));

@@ -88,16 +88,23 @@ struct brkSweepTurn {
   uint32_t flags() { return (turn++ & 1u) ? BRK_SWEEP_REVERSE : 0u; }
 };
 
-// new BrickStorage on the destination side holding a copy of the data
+// new BrickStorage on the destination side holding a copy of the data.  The device side comes from brk_storage_alloc (brk.h): the
+// storage is PLACED in HBM where streams between it and the storages moved before it run fastest (a sweep between two storages in
+// DRAM regions of the same kind loses 3 %), which the reference's one-cudaMalloc-per-storage leaves to chance.
 inline BrickStorage movBrickStorage(BrickStorage &bStorage, gpuMemcpyKind kind) {
   assert(kind == gpuMemcpyHostToDevice || kind == gpuMemcpyDeviceToHost);
   BrickStorage ret = bStorage;
   const size_t size = bStorage.step * (size_t)bStorage.chunks * sizeof(bElem);
   bElem *datptr;
   if (kind == gpuMemcpyHostToDevice) {
-    gpuCheck(gpuMalloc(&datptr, size));
+    void *placed = nullptr;
+    if (brk_storage_alloc(size, &placed, nullptr) != BRK_OK) {
+      printf("brk_storage_alloc: %s\n", brk_last_error());
+      exit(EXIT_FAILURE);
+    }
+    datptr = static_cast<bElem *>(placed);
     gpuCheck(gpuMemcpy(datptr, bStorage.dat.get(), size, kind));
-    ret.dat = std::shared_ptr<bElem>(datptr, [](bElem *p) { (void)gpuFree(p); });
+    ret.dat = std::shared_ptr<bElem>(datptr, [](bElem *p) { (void)brk_storage_free(p); });
   } else {
     datptr = (bElem *)malloc(size);
     gpuCheck(gpuMemcpy(datptr, bStorage.dat.get(), size, kind));

@@ -62,7 +62,7 @@ const char *brk_last_error(void);
 /* version of this ABI: 1000 + additions (1001: brk_stencil_apply_taps, 1002: the fused double-sweep stencil ids,
  * 1003: the ghost-zone exchange: brk_xplan_*, brk_exchange_*, brk_comm_*; 1004: brk_adjacency_register / _release;
  * 1005: brk_stencil_apply_{range,list,box}_ex with BRK_SWEEP_* flags; 1006: brk_comm_library, the development knob
- * brk_set_variant is no longer part of the ABI) */
+ * brk_set_variant is no longer part of the ABI; 1007: brk_storage_alloc / brk_storage_free / brk_placement_probe) */
 int brk_abi_version(void);
 /* radius / number of coefficients / communication-avoiding sweeps per exchange (ST_ITER, fake.h:39-344) */
 int brk_stencil_radius(int stencil_id);
@@ -166,6 +166,27 @@ typedef struct {
   uint64_t bytes;
 } brk_link;
 int brk_link_copy(const brk_link *links_dev, uint32_t n, uint64_t max_bytes, brk_stream s);
+
+/* ---- placement of brick storages in HBM -----------------------------------------------------------------------------
+ * The reference allocates device storage for a field wherever the allocator puts it (BrickStorage::allocate,
+ * include/brick.h:68-75; movBrickStorage, include/brick-gpu.h:80-99: one cudaMalloc per storage).  On MI355X that leaves
+ * 2.7 % of a bandwidth-bound sweep to chance: HBM is made of regions of about 8 GiB, and when a sweep's input and output
+ * storages lie in regions of the same kind its read and write streams meet in the same DRAM banks (7-point, 512^3: 0.371 ms
+ * against 0.361 ms; profiles/r04_g_*).  brk_storage_alloc is hipMalloc + a measurement: storages of at least 64 MiB are
+ * placed where a streaming copy from the (two) storages allocated before them into the new one runs fastest: up to 10
+ * candidate allocations (at most 16 GiB of them) are measured, all but the best are freed before the call returns.
+ * Synchronous, about 50 ms per storage; meant for set-up.  Memory from brk_storage_alloc is released with brk_storage_free.
+ * brk_placement_probe is the measurement itself (milliseconds per streaming copy of `bytes` from a to b on stream s; b is
+ * OVERWRITTEN) for callers that own their allocations (bricklib_amd places torch tensors with it).                      */
+typedef struct {
+  int candidates;           /* allocations measured (0: the storage was too small or had no partner, plain hipMalloc) */
+  int chosen;               /* index of the one kept */
+  double ms_per_gib_chosen; /* streaming copy from the slowest partner into the chosen candidate, per GiB */
+  double ms_per_gib_worst;  /* ... into the slowest candidate seen */
+} brk_placement;
+int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *report /* may be NULL */);
+int brk_storage_free(void *p_dev);
+int brk_placement_probe(const void *a_dev, void *b_dev, size_t bytes, brk_stream s, double *ms_per_copy);
 
 /* ---- array <-> brick (device) ------------------------------------------------------------------------------------
  * copyToBrick / copyFromBrick (include/bricksetup.h:172-221, iteration space :92-159): dimlist = iterated

@@ -168,6 +168,15 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     }
     return;
   }
+  if (name.find("k_place_copy") != std::string::npos) { // (a, b, n16): the streaming copy of brk_placement_probe / brk_storage_alloc
+    const void *a = arg<const void *>(args, 0);
+    void *b = arg<void *>(args, 1);
+    const size_t n16 = arg<size_t>(args, 2);
+    need("placement probe source", a, n16 * 16);
+    need("placement probe destination", b, n16 * 16);
+    std::memcpy(b, a, n16 * 16); // overlapping storages would be an ASan report
+    return;
+  }
   if (name.find("k_star_taps<") != std::string::npos) { // (adj, in, out, step, ids, first, n, StarTaps)
     const brklib::StarTaps t = arg<brklib::StarTaps>(args, 7);
     std::vector<int> off;
@@ -252,6 +261,19 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
       const uint32_t *linkmask = arg<const uint32_t *>(args, 9);
       if (linkmask)
         for (uint32_t b : list) need("link mask", linkmask + 4 * (size_t)(b >> 6), 16);
+      // box entry point over a registered table: a set bit promises that the row the kernel computes IS the row of the table
+      const uint32_t *cubemask = arg<const uint32_t *>(args, 10);
+      const uint32_t cs1 = arg<uint32_t>(args, 11), cs2 = arg<uint32_t>(args, 12);
+      if (cubemask)
+        for (uint32_t b : list) {
+          need("cube regularity mask", cubemask + (b >> 5), 4);
+          if (!((cubemask[b >> 5] >> (b & 31)) & 1u)) continue;
+          for (int q = 0; q < 27; ++q)
+            if (adj[(size_t)b * 27 + q] != b + (uint32_t)(q / 9 - 1) * cs2 + (uint32_t)((q / 3) % 3 - 1) * cs1 + (uint32_t)(q % 3 - 1)) {
+              fprintf(stderr, "hipmock: cube regularity bit set for brick %u whose entry %d is not the predicted one\n", b, q);
+              abort();
+            }
+        }
       // the kernel cannot tell BRK_MPI7_X2 from BRK_7PT_X2 either: both arrive as 25 weights
       run_stencil(ta.at(0) == 0 ? BRK_27PT_COEFF : (ta.at(0) == 1 ? BRK_MPI125 : BRK_MPI7_X2), adj, in, out, step, list, cf);
       return;
@@ -282,6 +304,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     const uint32_t nb = arg<uint32_t>(args, 1);
     const uint32_t s1 = reg ? arg<uint32_t>(args, 2) : 0, s2 = reg ? arg<uint32_t>(args, 3) : 0;
     uint32_t *mask = arg<uint32_t *>(args, reg ? 4 : 2);
+    const int cube = reg ? arg<int>(args, 5) : 0;
     need("adjacency table", adj, (size_t)nb * 27 * 4);
     using brklib::adj_slot;
     // what the launch writes: per wave of 64 threads two (regular) or four (link) words, also for the waves past nbricks
@@ -297,9 +320,13 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     for (uint32_t b = 0; b < nb; ++b) {
       const uint32_t *row = adj + (size_t)b * 27;
       if (reg) {
-        const bool ok = row[adj_slot(0, 0, -1)] == b - 1 && row[adj_slot(0, 0, 1)] == b + 1 && row[adj_slot(0, -1, 0)] == b - s1 &&
-                        row[adj_slot(0, 1, 0)] == b + s1 && row[adj_slot(-1, 0, 0)] == b - s2 && row[adj_slot(1, 0, 0)] == b + s2 && b >= s2 &&
-                        b + s2 < nb;
+        bool ok = row[adj_slot(0, 0, -1)] == b - 1 && row[adj_slot(0, 0, 1)] == b + 1 && row[adj_slot(0, -1, 0)] == b - s1 &&
+                  row[adj_slot(0, 1, 0)] == b + s1 && row[adj_slot(-1, 0, 0)] == b - s2 && row[adj_slot(1, 0, 0)] == b + s2 && b >= s2 &&
+                  b + s2 < nb;
+        if (cube) {
+          ok = ok && b >= s2 + s1 + 1 && (uint64_t)b + s2 + s1 + 1 < nb;
+          for (int q = 0; q < 27 && ok; ++q) ok = row[q] == b + (uint32_t)(q / 9 - 1) * s2 + (uint32_t)((q / 3) % 3 - 1) * s1 + (uint32_t)(q % 3 - 1);
+        }
         if (ok) mask[b >> 5] |= 1u << (b & 31);
       } else {
         const uint32_t l = row[adj_slot(0, 0, -1)], r = row[adj_slot(0, 0, 1)];
@@ -490,7 +517,14 @@ hipError_t hipEventQuery(hipEvent_t e) {
 }
 hipError_t hipEventSynchronize(hipEvent_t e) { return hipEventQuery(e); }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) {
-  *ms = 1.0f;
+  // successive intervals differ, so that code which chooses by measured time (brk_storage_alloc) does not always take the first
+  static int turn = 0;
+  static const float pattern[5] = {1.0f, 0.9f, 1.1f, 0.8f, 1.05f};
+  *ms = pattern[turn++ % 5];
+  return hipSuccess;
+}
+hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
+  *free_b = (size_t)64 << 30, *total_b = (size_t)288 << 30;
   return hipSuccess;
 }
 

@@ -194,7 +194,32 @@ static int launches() {
   return 0;
 }
 
+// brk_storage_alloc / brk_storage_free / brk_placement_probe: small storages (plain allocation), measured ones (candidates, all but one
+// freed again), storages of different sizes as partners, double free refused
+static int placement() {
+  void *small = nullptr, *a = nullptr, *b = nullptr, *c = nullptr;
+  brk_placement rep;
+  const size_t big = (size_t)65 << 20;
+  const unsigned long live0 = hipmock_live_allocations();
+  REQ(brk_storage_alloc(4096, &small, &rep) == BRK_OK && small && rep.candidates == 0);
+  REQ(brk_storage_alloc(big, &a, &rep) == BRK_OK && a && rep.candidates == 0); // nothing to place it against yet
+  REQ(brk_storage_alloc(big + 4096, &b, &rep) == BRK_OK && b && rep.candidates >= 2 && rep.chosen >= 0 && rep.chosen < rep.candidates &&
+      rep.ms_per_gib_chosen > 0 && rep.ms_per_gib_chosen <= rep.ms_per_gib_worst);
+  REQ(brk_storage_alloc(big - 4096, &c, nullptr) == BRK_OK && c);
+  REQ(hipmock_live_allocations() == live0 + 4); // the rejected candidates are gone
+  double ms = 0.0;
+  REQ(brk_placement_probe(a, b, big, nullptr, &ms) == BRK_OK && ms > 0.0);
+  REQ(brk_placement_probe(a, (char *)b + 8, 4096, nullptr, &ms) != BRK_OK); // misaligned
+  REQ(brk_placement_probe(nullptr, b, 4096, nullptr, &ms) != BRK_OK);
+  REQ(brk_storage_free(b) == BRK_OK && brk_storage_free(b) != BRK_OK); // second free: not ours any more
+  REQ(brk_storage_free(a) == BRK_OK && brk_storage_free(c) == BRK_OK && brk_storage_free(small) == BRK_OK && brk_storage_free(nullptr) == BRK_OK);
+  REQ(brk_storage_alloc(0, &a, nullptr) != BRK_OK && brk_storage_alloc(4096, nullptr, nullptr) != BRK_OK);
+  REQ(hipmock_live_allocations() == live0);
+  return 0;
+}
+
 int main() {
+  if (placement()) return 1;
   const uint32_t shapes[][3] = {{16, 16, 16}, {32, 16, 24}, {24, 40, 16}};
   for (auto &sh : shapes)
     for (int world : {1, 2, 3, 4, 5, 8, 12})

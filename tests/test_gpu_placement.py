@@ -1,0 +1,95 @@
+"""Placement of brick storages in HBM (brk_storage_alloc / brk_placement_probe, include/brk.h; bricklib_amd.BrickStorage.allocate).
+Needs an MI355X.  What is held here: a placed storage is an ordinary tensor over memory the library owns, results do not depend on
+where a storage lies, the memory goes back when the tensor dies, and the measurement behind the choice is a real one."""
+import ctypes as C
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+import bricklib_amd as bl
+from bricklib_amd._lib import Placement, lib
+from bricklib_amd.brick import grid_to_device
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_placed_storages_are_tensors_and_results_do_not_depend_on_placement(dev, monkeypatch):
+    """a 22^3-brick grid with step 1024 is 87 MB per storage: large enough to be measured (64 MiB), small enough for a quick test"""
+    SB = 22
+    grid, info = bl.init_grid((SB, SB, SB), dev)
+    ids = grid_to_device(np.ascontiguousarray(grid.reshape(SB, SB, SB)[1:-1, 1:-1, 1:-1]).reshape(-1), dev)
+    outs = {}
+    for placed in ("1", "0"):
+        monkeypatch.setenv("BRK_PLACEMENT", placed)
+        a, b = bl.BrickStorage.allocate(info.nbricks, 1024, dev), bl.BrickStorage.allocate(info.nbricks, 1024, dev)
+        assert a.dat.dtype == torch.float64 and a.dat.numel() == info.nbricks * 1024 and a.dat.is_contiguous()
+        assert float(a.dat.abs().max()) == 0.0 and float(b.dat.abs().max()) == 0.0      # allocate() hands out zeroed storages
+        if placed == "1":
+            assert a.placement is not None and b.placement is not None
+            assert b.placement["candidates"] >= 2 and 0 <= b.placement["chosen"] < b.placement["candidates"]
+            assert 0.0 < b.placement["ms_per_gib_chosen"] <= b.placement["ms_per_gib_worst"]
+        else:
+            assert a.placement is None and b.placement is None
+        g = torch.Generator(device=dev).manual_seed(7)
+        a.dat.copy_(torch.rand(a.dat.numel(), generator=g, device=dev, dtype=torch.float64))
+        for name in ("7pt", "mpi13pt", "mpi125pt"):
+            coeff = np.linspace(0.1, 1.0, 129) if name == "7pt" else None
+            bl.apply_stencil(name, bl.Brick(info, a, 0), bl.Brick(info, b, 0), ids=ids, coeff=coeff)
+            torch.cuda.synchronize()
+            outs[(placed, name)] = b.dat.clone()
+        # views, slices and arithmetic behave as on any tensor
+        assert bl.Brick(info, b, 512).dat.data_ptr() == b.dat.data_ptr() + 512 * 8
+        del a, b
+    for name in ("7pt", "mpi13pt", "mpi125pt"):
+        assert torch.equal(outs[("1", name)], outs[("0", name)])
+
+
+def test_placed_memory_is_returned_with_the_tensor(dev, monkeypatch):
+    monkeypatch.setenv("BRK_PLACEMENT", "1")
+    gc.collect()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    nbytes = 96 << 20
+    sts = [bl.BrickStorage.allocate(nbytes // 8 // 512, 512, dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free1 >= 3 * nbytes * 0.95            # three storages are held, the rejected candidates are not
+    assert free0 - free1 <= 3 * nbytes + (64 << 20)
+    view = sts[1].dat[1000:2000]                         # a view keeps its storage alive
+    del sts
+    gc.collect()
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free2 >= nbytes * 0.95 and free0 - free2 <= nbytes + (64 << 20)
+    assert float(view.sum()) == 0.0
+    del view
+    gc.collect()
+    torch.cuda.synchronize()
+    free3, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free3 <= (32 << 20)
+
+
+def test_placement_probe_and_c_abi_allocator(dev):
+    nbytes = 128 << 20
+    a, b = C.c_void_p(), C.c_void_p()
+    rep = Placement()
+    with torch.cuda.device(dev):
+        assert lib.brk_storage_alloc(nbytes, C.byref(a), C.byref(rep)) == 0 and a.value
+        assert lib.brk_storage_alloc(nbytes, C.byref(b), C.byref(rep)) == 0 and b.value and b.value != a.value
+        assert rep.candidates >= 2 and rep.ms_per_gib_chosen > 0.0
+        ms = C.c_double()
+        assert lib.brk_placement_probe(a, b, nbytes, None, C.byref(ms)) == 0
+        # 128 MiB read + 128 MiB written: between 3 and 12 TB/s of traffic would be 0.02-0.09 ms; anything from 0.01 to 1 ms is a measurement
+        assert 0.01 < ms.value < 1.0
+        assert abs(ms.value * 8 - rep.ms_per_gib_chosen) / rep.ms_per_gib_chosen < 0.5      # the same copy, the same rate (1 GiB = 8 x 128 MiB)
+        assert lib.brk_placement_probe(a, C.c_void_p(b.value + 8), 4096, None, C.byref(ms)) != 0
+        assert lib.brk_storage_free(a) == 0 and lib.brk_storage_free(a) != 0
+        assert lib.brk_storage_free(b) == 0

@@ -226,6 +226,12 @@ pair7)   # 7-point: two bricks per wave (variants 7 / 8 / 9, dev build) over k-p
   run -n 512 -s 0 -S -o 4 -J -G 4 -v 107 -i 60 -r2 2
   run -n 512 -s 0 -S -o 2 -J -G 4 -v 107 -i 60 -r2 2
   run -n 512 -s 0 -S -b -v 100 -i 60 -r2 3 ;;
+predrow) # DEV=1 build: cube kernels, box entry point over a registered table -- adjacency rows computed for bricks whose 26 neighbours are the predicted ids (100) vs every row loaded (125600)
+  for sid in 1 5 7; do run -n 512 -s $sid -S -b -v 100,125600 -i 40 -r2 4; done ;;
+shift7)  # 7-point box kernel: the output storage shifted against the input storage (does the DRAM channel / bank alignment of the two streams matter?)
+  for A in ${SHIFTS:-0 256 1024 4096 8192 32768 69632 1052672 0}; do run -n 512 -s ${SID:-0} -S -b -v 100 -i ${IT:-100} -r2 2 ${AOPT:--A} $A; done ;;
+place7)  # 7-point box kernel over freshly allocated output storages in ONE process: does the physical placement matter?
+  run -n 512 -s ${SID:-0} -S -b -v 100 -i ${IT:-60} ${TOPT:--T} ${TRIALS:-24} ;;
 reg7)    # 7-point box kernel with / without brk_adjacency_register
   for r in 1 2 3; do run -n 512 -s 0 -S -b -v 0 -i 60; run -n 512 -s 0 -S -b -v 0 -i 60 -R; done ;;
 order7)  # 7-point list form: rows per block of the XCD slab order

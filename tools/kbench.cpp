@@ -162,6 +162,10 @@ int main(int argc, char **argv) {
   int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1, rounds = 2;
   bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false, reg = false, kpair = false, jpair = false, zigzag = false;
   long run = 4, nlev = 2; // -P / -J: entries per run; -P: k-levels per group (-K)
+  bool one_alloc = false;
+  int trials = 0;
+  bool trial_copy = false;
+  size_t out_shift = 0;   // -A: the output storage starts this many bytes into its allocation (DRAM channel / bank alignment of out against in)
   std::vector<int> variants = {1, 2, 5};
   for (int a = 1; a < argc; ++a) {
     std::string o = argv[a];
@@ -181,6 +185,10 @@ int main(int argc, char **argv) {
     else if (o == "-K") nlev = atol(argv[++a]); // with -P: k-levels per group (2 = pairs, 4 = the k-stacked order of k_star_km)
     else if (o == "-R") reg = true;        // brk_adjacency_register: the table is promised immutable
     else if (o == "-Z") zigzag = true;     // list form: every other launch walks each XCD's share of the list backwards (groups of 8 kept)
+    else if (o == "-A") out_shift = (size_t)atol(argv[++a]);
+    else if (o == "-Tc") { trials = atoi(argv[++a]); trial_copy = true; } // the same with a plain brick copy (non-temporal stores) instead of the stencil
+    else if (o == "-T") trials = atoi(argv[++a]); // placement trials: the variant list is timed over `trials` freshly allocated output storages (earlier ones stay allocated)
+    else if (o == "-A1") { one_alloc = true; out_shift = (size_t)atol(argv[++a]); } // in and out carved out of ONE allocation: out = in + round_up(size, 2 MiB) + shift
     else if (o == "-c") stream = true;     // also run the streaming-ceiling kernels
     else if (o == "-D") {                  // diagnostic builds of libbrk.so: timing experiment of the 7-point box kernel
       typedef void (*diag_fn)(int);
@@ -269,11 +277,23 @@ int main(int argc, char **argv) {
   double *st_in, *st_out, *st_ref;
   uint32_t *adj_d, *ids_d = nullptr;
   unsigned long long *res_d;
-  CK(hipMalloc(&st_in, elems * 8));
-  if (decomp || separate) {
-    CK(hipMalloc(&st_out, elems * 8));
+  const size_t field_2m = (elems * 8 + (2u << 20) - 1) / (2u << 20) * (2u << 20);
+  if (one_alloc && (decomp || separate)) {
+    char *raw;
+    CK(hipMalloc(&raw, 2 * field_2m + out_shift));
+    st_in = (double *)raw;
+    st_out = (double *)(raw + field_2m + out_shift);
     CK(hipMalloc(&st_ref, elems * 8));
+    printf("# one allocation %p: out - in = %zu B\n", (void *)raw, field_2m + out_shift);
+  } else if (decomp || separate) {
+    CK(hipMalloc(&st_in, elems * 8));
+    char *raw;
+    CK(hipMalloc(&raw, elems * 8 + out_shift));
+    st_out = (double *)(raw + out_shift);
+    CK(hipMalloc(&st_ref, elems * 8));
+    printf("# in %p out %p: out - in = %td B\n", (void *)st_in, (void *)st_out, (char *)st_out - (char *)st_in);
   } else {
+    CK(hipMalloc(&st_in, elems * 8));
     st_out = st_in + 512; // interleaved second field (stencils/3axis.cpp:25-28)
     CK(hipMalloc(&st_ref, elems * 8));
   }
@@ -365,16 +385,70 @@ int main(int argc, char **argv) {
   // that variant's launches, 2xx = diagnostic build, diag 1, 3xx = registered + diag 16
   typedef void (*diag_fn2)(int);
   diag_fn2 set_diag = (diag_fn2)dlsym(RTLD_DEFAULT, "brk_debug_diag");
+  if (trials > 0 && (decomp || separate)) {
+    // does the PLACEMENT of the two storages matter?  Same process, same kernel: `trials` freshly allocated storages (all kept), the
+    // sweep timed from storage A into storage B for A = the original input and two of the fresh ones
+    BK(brk_adjacency_register(adj_d, nbricks));
+    std::vector<double *> buf = {st_in, st_out, st_ref};
+    for (int t = 0; t < trials; ++t) {
+      char *raw;
+      CK(hipMalloc(&raw, elems * 8));
+      buf.push_back((double *)raw);
+    }
+    auto timed = [&](const double *src, double *dst) {
+      auto go = [&]() {
+        uint32_t SBu = (uint32_t)(N / 8 + 2), tot[3] = {SBu, SBu, SBu}, lo3[3] = {1, 1, 1}, cnt[3] = {SBu - 2, SBu - 2, SBu - 2};
+        if (trial_copy) k_stream2_range_nt<0><<<(nbricks + 3) / 4, 256>>>(src, dst, step, 0, nbricks);
+        else if (boxmode) BK(brk_stencil_apply_box(sid, adj_d, src, dst, step, 0, tot, lo3, cnt, cp, nullptr));
+        else BK(brk_stencil_apply_list(sid, adj_d, src, dst, step, ids_d, nlist, cp, nullptr));
+      };
+      for (int w = 0; w < 5; ++w) go();
+      float best = 1e9f;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0));
+        for (int it = 0; it < iters; ++it) go();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms / iters);
+      }
+      return best;
+    };
+    const size_t srcs[3] = {0, buf.size() / 3, 2 * buf.size() / 3};
+    for (size_t si : srcs) {
+      k_fill<<<4096, 256>>>(buf[si], elems, 1);
+      CK(hipDeviceSynchronize());
+      for (size_t t = 0; t < buf.size(); ++t) {
+        if (t == si) continue;
+        const float ms = timed(buf[si], buf[t]);
+        printf("in = storage %2zu (%p)  out = storage %2zu (%p), out - in %+8.3f GiB  %.4f ms\n", si, (void *)buf[si], t, (void *)buf[t],
+               ((char *)buf[t] - (char *)buf[si]) / 1073741824.0, ms);
+        fflush(stdout);
+      }
+    }
+    (void)hipDeviceSynchronize();
+    brk_adjacency_release(adj_d);
+    return 0;
+  }
   for (int round = 0; round < rounds; ++round)
     for (int vcode : variants) {
-      const int v = vcode % 100, mode = vcode / 100;
-      if (mode == 1 || mode == 3) BK(brk_adjacency_register(adj_d, nbricks));
-      if (set_diag && mode >= 2 && mode < 10) set_diag(mode == 2 ? 1 : 16);
-      if (set_diag && mode >= 10) set_diag(mode - 10); // 10xx + 100 * bits: ablation bits of the cube kernels (diagnostic builds)
+      const int v = vcode % 100;
+      int mode = vcode / 100;
+      const bool reg_diag = mode >= 1000; // 1000xx + 100 * bits: registered table AND development bits (DEV=1 builds: 256 = cube kernels load every adjacency row)
+      if (reg_diag) {
+        BK(brk_adjacency_register(adj_d, nbricks));
+        if (set_diag) set_diag(mode - 1000);
+        mode = 1;
+      } else {
+        if (mode == 1 || mode == 3) BK(brk_adjacency_register(adj_d, nbricks));
+        if (set_diag && mode >= 2 && mode < 10) set_diag(mode == 2 ? 1 : 16);
+        if (set_diag && mode >= 10) set_diag(mode - 10); // 10xx + 100 * bits: ablation bits of the cube kernels (diagnostic builds)
+      }
       struct Undo {
-        int mode; const uint32_t *adj; diag_fn2 sd;
-        ~Undo() { if (mode == 1 || mode == 3) { (void)hipDeviceSynchronize(); brk_adjacency_release(adj); } if (sd && mode >= 2) sd(0); }
-      } undo{mode, adj_d, set_diag};
+        int mode; const uint32_t *adj; diag_fn2 sd; bool rd;
+        ~Undo() { if (mode == 1 || mode == 3) { (void)hipDeviceSynchronize(); brk_adjacency_release(adj); } if (sd && (mode >= 2 || rd)) sd(0); }
+      } undo{mode, adj_d, set_diag, reg_diag};
       if (brk_set_variant(sid, v) != BRK_OK) {
         printf("variant %d  not in this build of libbrk.so (make -C bricklib_amd/csrc VARIANTS=1)\n", vcode);
         continue;
