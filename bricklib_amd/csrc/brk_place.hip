@@ -1,17 +1,18 @@
 // brk_place.hip -- WHERE in HBM the brick storages of a process lie (brk_storage_alloc / brk_storage_free / brk_placement_probe).
 //
-// Measured on MI355X (profiles/r04_g_*): the 288 GB are made of regions of roughly 8 GiB, and a sweep whose input storage and
-// output storage lie in regions of the same kind runs 2.7 % slower (7-point, 512^3: 0.371-0.372 ms against 0.361-0.362 ms; a
-// brick-shaped copy: 0.400 against 0.386 ms) than the same sweep between storages in regions of different kinds -- the read
-// stream and the write stream then meet in the same DRAM banks.  Which region a hipMalloc lands in is the driver's business and
-// is not visible from the virtual address: storages allocated one after the other are usually of the same kind (8 consecutive
-// 1.1-GiB allocations were), sometimes not, which is the "fast box / slow box" spread of the earlier rounds' numbers.
+// Measured on MI355X (profiles/r04_g_*): for a bandwidth-bound sweep the device allocations of a process fall into two kinds, and a
+// sweep whose input storage and output storage are of the same kind runs 2.5-3 % slower (7-point, 512^3: 0.368-0.372 ms against
+// 0.359-0.362 ms, every pair of 33 storages of 1.1 GiB in one process) than between storages of different kinds -- presumably the
+// read stream and the write stream then meet in the same DRAM banks; no counter of this profiler shows it.  Which kind a hipMalloc
+// gets is the driver's business and is not visible from the virtual address: storages allocated one after the other are mostly of
+// the same kind (runs of 3 to 11 consecutive 1.1-GiB allocations), sometimes not -- the "fast box / slow box" spread of the earlier
+// rounds' numbers.
 // The reference allocates a storage wherever the allocator puts it (include/brick.h:68-75, include/brick-gpu.h:80-99); here
-// the allocator of brick storages MEASURES: up to ten candidate allocations are made, a streaming copy from the storages allocated
-// before into each candidate is timed, the candidate with the fastest copy is kept and the others are freed (all candidates are
-// held until the choice is made, so each one lies somewhere else).  Pairs differ by more than two levels (copy: 0.397 ... 0.454 ms
-// per GiB between 32 storages of one process, reproducible to 1 %), so every candidate is measured rather than the first fast one
-// taken.  About 50 ms per storage, at setup.
+// the allocator of brick storages MEASURES: candidate allocations are made (6 to 24, all held until the choice is made so that each
+// lies somewhere else), a 7-point sweep from the storages allocated before into each candidate is timed, the candidate with the
+// fastest sweep is kept and the others are freed.  For the sweep the storages of a process fall into two kinds (same kind: slow,
+// different kinds: fast; clean to 0.3 %); the search stops once both rates have been seen among at least six candidates.
+// 50-150 ms per storage, at setup.
 #include <algorithm>
 #include <cstring>
 #include <mutex>
@@ -22,15 +23,6 @@
 namespace brklib {
 namespace {
 
-// read stream from a, write stream into b, 16 bytes per lane, results leave with non-temporal stores (as the sweeps' do)
-__global__ __launch_bounds__(256) void k_place_copy(const uint4 *__restrict__ a, uint4 *__restrict__ b, size_t n16) {
-  typedef unsigned v4 __attribute__((ext_vector_type(4)));
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) {
-    const v4 v = reinterpret_cast<const v4 *>(a)[i];
-    __builtin_nontemporal_store(v, reinterpret_cast<v4 *>(b) + i);
-  }
-}
-
 struct Placed {
   void *p;
   size_t bytes;
@@ -40,12 +32,39 @@ std::mutex g_place_mutex;
 std::vector<Placed> g_placed; // live storages handed out by brk_storage_alloc, in allocation order
 
 constexpr size_t kMinPlaced = (size_t)64 << 20;      // smaller storages are not worth a measurement
-constexpr size_t kCandidateBudget = (size_t)16 << 30; // address space / memory held by candidates while one storage is placed
-constexpr int kMaxCandidates = 10;                   // 8 consecutive allocations of one kind were seen
+constexpr size_t kCandidateBudget = (size_t)28 << 30; // memory held by candidates while one storage is placed
+constexpr int kMinCandidates = 6, kMaxCandidates = 24; // runs of up to 11 consecutive allocations of one kind were seen
+constexpr double kBothKindsSeen = 0.985;               // the two sweep rates are 2.5-3 % apart, repeats of one pair within 0.3 %
+constexpr uint32_t kMaxProbeEdge = 82;                 // bricks per axis of the probe grid: at most 82^3 x 4 KiB = 2.3 GB swept per launch
 
-int probe_locked(const void *a, void *b, size_t bytes, hipStream_t st, double *ms_out) {
-  const size_t n16 = bytes / 16;
-  if (n16 == 0) return brk_fail(BRK_EINVAL, "brk_placement_probe: fewer than 16 bytes");
+// The measurement is the production sweep itself: the 7-point stencil (brk_stencil_apply_box, the kernel behind the headline) from
+// storage a into storage b over the largest cubic lexicographic brick grid both can hold, one brick of ghost ring around the swept
+// interior -- exactly the shape of the single/ driver.  A streaming copy was tried first and is NOT a substitute: between the same
+// pairs of storages a linear copy, brick copies in range order, in XCD eighths and in slab order all show several levels that only
+// partly follow the two levels of the sweep (profiles/r04_g_placement_probe_candidates.txt).
+struct ProbeGrid {
+  uint32_t edge = 0;
+  uint32_t *adj = nullptr; // device, [edge^3][27]
+  ~ProbeGrid() {
+    if (adj) (void)hipFree(adj);
+  }
+};
+
+int make_probe_grid(size_t bytes, ProbeGrid &g) {
+  const size_t nb = bytes / 4096;
+  uint32_t e = 3;
+  while ((size_t)(e + 1) * (e + 1) * (e + 1) <= nb && e < kMaxProbeEdge) ++e;
+  if ((size_t)e * e * e > nb) return brk_fail(BRK_EINVAL, "placement probe: %zu bytes hold fewer than 3 x 3 x 3 bricks", bytes);
+  std::vector<uint32_t> grid((size_t)e * e * e), adj((size_t)e * e * e * 27);
+  const long dims[3] = {(long)e, (long)e, (long)e};
+  if (int rc = brk_init_grid(dims, grid.data(), adj.data())) return rc;
+  HIP_TRY(hipMalloc(&g.adj, adj.size() * sizeof(uint32_t)));
+  HIP_TRY(hipMemcpy(g.adj, adj.data(), adj.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  g.edge = e;
+  return BRK_OK;
+}
+
+int probe_locked(const ProbeGrid &g, const void *a, void *b, hipStream_t st, double *ms_out) {
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   hipError_t r = hipEventCreate(&e1);
@@ -53,18 +72,20 @@ int probe_locked(const void *a, void *b, size_t bytes, hipStream_t st, double *m
     (void)hipEventDestroy(e0);
     HIP_TRY(r);
   }
-  const dim3 grid(4096), block(256);
-  constexpr int kWarm = 2, kTimed = 6;
-  for (int q = 0; q < kWarm; ++q) hipLaunchKernelGGL(k_place_copy, grid, block, 0, st, (const uint4 *)a, (uint4 *)b, n16);
-  r = hipEventRecord(e0, st);
-  for (int q = 0; q < kTimed && r == hipSuccess; ++q) hipLaunchKernelGGL(k_place_copy, grid, block, 0, st, (const uint4 *)a, (uint4 *)b, n16);
-  if (r == hipSuccess) r = hipEventRecord(e1, st);
-  if (r == hipSuccess) r = hipEventSynchronize(e1);
-  if (r == hipSuccess) r = hipGetLastError();
+  const uint32_t tot[3] = {g.edge, g.edge, g.edge}, lo[3] = {1, 1, 1}, cnt[3] = {g.edge - 2, g.edge - 2, g.edge - 2};
+  constexpr int kWarm = 3, kTimed = 10;
+  int rc = BRK_OK;
+  auto sweep = [&]() { return brk_stencil_apply_box(BRK_MPI7, g.adj, static_cast<const double *>(a), static_cast<double *>(b), 512, 0, tot, lo, cnt, nullptr, st); };
+  for (int q = 0; q < kWarm && rc == BRK_OK; ++q) rc = sweep();
+  if (rc == BRK_OK) r = hipEventRecord(e0, st);
+  for (int q = 0; q < kTimed && rc == BRK_OK && r == hipSuccess; ++q) rc = sweep();
+  if (rc == BRK_OK && r == hipSuccess) r = hipEventRecord(e1, st);
+  if (rc == BRK_OK && r == hipSuccess) r = hipEventSynchronize(e1);
   float ms = 0.f;
-  if (r == hipSuccess) r = hipEventElapsedTime(&ms, e0, e1);
+  if (rc == BRK_OK && r == hipSuccess) r = hipEventElapsedTime(&ms, e0, e1);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (rc) return rc;
   HIP_TRY(r);
   *ms_out = (double)ms / kTimed;
   return BRK_OK;
@@ -75,10 +96,12 @@ int probe_locked(const void *a, void *b, size_t bytes, hipStream_t st, double *m
 
 using namespace brklib;
 
-extern "C" int brk_placement_probe(const void *a_dev, void *b_dev, size_t bytes, brk_stream s, double *ms_per_copy) {
-  if (!a_dev || !b_dev || !ms_per_copy) return brk_fail(BRK_EINVAL, "brk_placement_probe: null argument");
+extern "C" int brk_placement_probe(const void *a_dev, void *b_dev, size_t bytes, brk_stream s, double *ms_per_sweep) {
+  if (!a_dev || !b_dev || !ms_per_sweep) return brk_fail(BRK_EINVAL, "brk_placement_probe: null argument");
   if (((uintptr_t)a_dev | (uintptr_t)b_dev) % 16) return brk_fail(BRK_EINVAL, "brk_placement_probe: storages must be 16-byte aligned");
-  return probe_locked(a_dev, b_dev, bytes, static_cast<hipStream_t>(s), ms_per_copy);
+  ProbeGrid g;
+  if (int rc = make_probe_grid(bytes, g)) return rc;
+  return probe_locked(g, a_dev, b_dev, static_cast<hipStream_t>(s), ms_per_sweep);
 }
 
 extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *report) {
@@ -101,6 +124,10 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     int ncand = (int)std::min<size_t>(kMaxCandidates, std::max<size_t>(2, kCandidateBudget / bytes));
     ncand = (int)std::min<size_t>((size_t)ncand, std::max<size_t>(1, free_b / 2 / bytes));
+    size_t probe_bytes = bytes; // one probe grid for all pairs: what the smallest storage involved can hold
+    for (const Placed &p : partners) probe_bytes = std::min(probe_bytes, p.bytes);
+    ProbeGrid grid;
+    if (int rc0 = make_probe_grid(probe_bytes, grid)) return rc0;
     std::vector<void *> cands;
     std::vector<double> score;
     int best = -1;
@@ -113,18 +140,20 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
         break;
       }
       cands.push_back(c);
-      double sc = 0.0; // milliseconds per GiB, worst partner
+      double sc = 0.0; // milliseconds per probe sweep, slowest partner
       for (const Placed &p : partners) {
-        const size_t nb = std::min(bytes, p.bytes);
         double ms = 0.0;
-        rc = probe_locked(p.p, c, nb, nullptr, &ms);
+        rc = probe_locked(grid, p.p, c, nullptr, &ms);
         if (rc) break;
-        sc = std::max(sc, ms * (double)((size_t)1 << 30) / (double)nb);
+        sc = std::max(sc, ms);
       }
       if (rc) break;
       score.push_back(sc);
       if (best < 0 || sc < score[best]) best = (int)score.size() - 1;
       worst = std::max(worst, sc);
+      // both rates have been seen and a few candidates of the fast kind compared: done.  Otherwise keep allocating -- runs of ten
+      // consecutive allocations of one kind occur
+      if ((int)score.size() >= kMinCandidates && score[best] <= kBothKindsSeen * worst) break;
     }
     if (rc || best < 0) {
       for (void *c : cands) (void)hipFree(c);
@@ -137,8 +166,9 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
     if (report) {
       report->candidates = (int)score.size();
       report->chosen = best;
-      report->ms_per_gib_chosen = score[best];
-      report->ms_per_gib_worst = worst;
+      report->probe_bricks = (int)((grid.edge - 2) * (grid.edge - 2) * (grid.edge - 2));
+      report->ms_chosen = score[best];
+      report->ms_worst = worst;
     }
   }
   g_placed.push_back({chosen, bytes, device});

@@ -168,15 +168,6 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     }
     return;
   }
-  if (name.find("k_place_copy") != std::string::npos) { // (a, b, n16): the streaming copy of brk_placement_probe / brk_storage_alloc
-    const void *a = arg<const void *>(args, 0);
-    void *b = arg<void *>(args, 1);
-    const size_t n16 = arg<size_t>(args, 2);
-    need("placement probe source", a, n16 * 16);
-    need("placement probe destination", b, n16 * 16);
-    std::memcpy(b, a, n16 * 16); // overlapping storages would be an ASan report
-    return;
-  }
   if (name.find("k_star_taps<") != std::string::npos) { // (adj, in, out, step, ids, first, n, StarTaps)
     const brklib::StarTaps t = arg<brklib::StarTaps>(args, 7);
     std::vector<int> off;

@@ -204,12 +204,13 @@ static int placement() {
   REQ(brk_storage_alloc(4096, &small, &rep) == BRK_OK && small && rep.candidates == 0);
   REQ(brk_storage_alloc(big, &a, &rep) == BRK_OK && a && rep.candidates == 0); // nothing to place it against yet
   REQ(brk_storage_alloc(big + 4096, &b, &rep) == BRK_OK && b && rep.candidates >= 2 && rep.chosen >= 0 && rep.chosen < rep.candidates &&
-      rep.ms_per_gib_chosen > 0 && rep.ms_per_gib_chosen <= rep.ms_per_gib_worst);
+      rep.ms_chosen > 0 && rep.ms_chosen <= rep.ms_worst && rep.probe_bricks == 23 * 23 * 23); // 65 MiB hold 25^3 bricks
   REQ(brk_storage_alloc(big - 4096, &c, nullptr) == BRK_OK && c);
   REQ(hipmock_live_allocations() == live0 + 4); // the rejected candidates are gone
   double ms = 0.0;
   REQ(brk_placement_probe(a, b, big, nullptr, &ms) == BRK_OK && ms > 0.0);
-  REQ(brk_placement_probe(a, (char *)b + 8, 4096, nullptr, &ms) != BRK_OK); // misaligned
+  REQ(brk_placement_probe(a, (char *)b + 8, big, nullptr, &ms) != BRK_OK); // misaligned
+  REQ(brk_placement_probe(a, b, 26 * 4096, nullptr, &ms) != BRK_OK);         // fewer than 3 x 3 x 3 bricks
   REQ(brk_placement_probe(nullptr, b, 4096, nullptr, &ms) != BRK_OK);
   REQ(brk_storage_free(b) == BRK_OK && brk_storage_free(b) != BRK_OK); // second free: not ours any more
   REQ(brk_storage_free(a) == BRK_OK && brk_storage_free(c) == BRK_OK && brk_storage_free(small) == BRK_OK && brk_storage_free(nullptr) == BRK_OK);

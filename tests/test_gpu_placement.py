@@ -35,7 +35,11 @@ def test_placed_storages_are_tensors_and_results_do_not_depend_on_placement(dev,
         if placed == "1":
             assert a.placement is not None and b.placement is not None
             assert b.placement["candidates"] >= 2 and 0 <= b.placement["chosen"] < b.placement["candidates"]
-            assert 0.0 < b.placement["ms_per_gib_chosen"] <= b.placement["ms_per_gib_worst"]
+            assert 0.0 < b.placement["probe_sweep_ms_chosen"] <= b.placement["probe_sweep_ms_worst"]
+            edge = int(round((info.nbricks * 2) ** (1 / 3))) + 1   # the probe sweeps the interior of the largest cubic grid of 4-KiB bricks that fits
+            while edge ** 3 > info.nbricks * 2:
+                edge -= 1
+            assert b.placement["probe_bricks"] == (edge - 2) ** 3
         else:
             assert a.placement is None and b.placement is None
         g = torch.Generator(device=dev).manual_seed(7)
@@ -84,12 +88,13 @@ def test_placement_probe_and_c_abi_allocator(dev):
     with torch.cuda.device(dev):
         assert lib.brk_storage_alloc(nbytes, C.byref(a), C.byref(rep)) == 0 and a.value
         assert lib.brk_storage_alloc(nbytes, C.byref(b), C.byref(rep)) == 0 and b.value and b.value != a.value
-        assert rep.candidates >= 2 and rep.ms_per_gib_chosen > 0.0
+        assert rep.candidates >= 6 and rep.ms_chosen > 0.0 and rep.probe_bricks == 30 ** 3      # 128 MiB = 32768 bricks = 32^3
         ms = C.c_double()
         assert lib.brk_placement_probe(a, b, nbytes, None, C.byref(ms)) == 0
-        # 128 MiB read + 128 MiB written: between 3 and 12 TB/s of traffic would be 0.02-0.09 ms; anything from 0.01 to 1 ms is a measurement
+        # 27000 bricks swept: 110 MB read + 110 MB written; between 2 and 12 TB/s that is 0.02-0.11 ms; anything from 0.01 to 1 ms is a measurement
         assert 0.01 < ms.value < 1.0
-        assert abs(ms.value * 8 - rep.ms_per_gib_chosen) / rep.ms_per_gib_chosen < 0.5      # the same copy, the same rate (1 GiB = 8 x 128 MiB)
-        assert lib.brk_placement_probe(a, C.c_void_p(b.value + 8), 4096, None, C.byref(ms)) != 0
+        assert abs(ms.value - rep.ms_chosen) / rep.ms_chosen < 0.3      # the same sweep between the same storages
+        assert lib.brk_placement_probe(a, C.c_void_p(b.value + 8), nbytes - 4096, None, C.byref(ms)) != 0
+        assert lib.brk_placement_probe(a, b, 26 * 4096, None, C.byref(ms)) != 0
         assert lib.brk_storage_free(a) == 0 and lib.brk_storage_free(a) != 0
         assert lib.brk_storage_free(b) == 0

@@ -158,6 +158,24 @@ __global__ __launch_bounds__(256) void k_stream2_persist(const double *in, doubl
   }
 }
 
+// candidate placement probes (development): brick copy in the sweep's shape -- planes of PB bricks walked in order, XCD x (= blockIdx & 7)
+// takes the x-th eighth of every plane, one wave per brick, NW waves per workgroup, non-temporal stores
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_probe_slab(const double *in, double *out, uint32_t nb, uint32_t PB) {
+  const uint32_t per_xcd = gridDim.x >> 3, x = blockIdx.x & 7u, local = blockIdx.x >> 3;
+  const uint32_t s = local * NW + (threadIdx.x >> 6); // position inside this XCD's share
+  const uint32_t share = PB / 8, plane = s / share, off = s % share;
+  const uint32_t b = plane * PB + x * share + off;
+  (void)per_xcd;
+  if (b >= nb) return;
+  const int lane = threadIdx.x & 63;
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = in[(size_t)b * 512 + k * 64 + lane];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) __builtin_nontemporal_store(v[k] * 1.0001, &out[(size_t)b * 512 + k * 64 + lane]);
+}
+
 int main(int argc, char **argv) {
   int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1, rounds = 2;
   bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false, reg = false, kpair = false, jpair = false, zigzag = false;
@@ -422,8 +440,25 @@ int main(int argc, char **argv) {
       for (size_t t = 0; t < buf.size(); ++t) {
         if (t == si) continue;
         const float ms = timed(buf[si], buf[t]);
-        printf("in = storage %2zu (%p)  out = storage %2zu (%p), out - in %+8.3f GiB  %.4f ms\n", si, (void *)buf[si], t, (void *)buf[t],
-               ((char *)buf[t] - (char *)buf[si]) / 1073741824.0, ms);
+        double probe_ms = 0.0; // the library's own placement measurement of the same pair (overwrites buf[t]: fine, it is an output)
+        BK(brk_placement_probe(buf[si], buf[t], elems * 8, nullptr, &probe_ms));
+        auto time_k = [&](auto go) {
+          for (int w = 0; w < 2; ++w) go();
+          CK(hipEventRecord(e0));
+          for (int it = 0; it < 6; ++it) go();
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          float m2;
+          CK(hipEventElapsedTime(&m2, e0, e1));
+          return m2 / 6;
+        };
+        const uint32_t nb = nbricks;
+        const float c_range = time_k([&]() { k_stream2_range_nt<0><<<(nb + 3) / 4, 256>>>(buf[si], buf[t], 512, 0, nb); });
+        const float c_xcd8 = time_k([&]() { k_stream2_xcd_nt<8, 1><<<(((nb + 7) / 8 + 7) / 8) * 8, 512>>>(buf[si], buf[t], 512, 0, nb); });
+        const float c_slab = time_k([&]() { k_probe_slab<8><<<(((nb + 7) / 8 + 7) / 8) * 8, 512>>>(buf[si], buf[t], nb, 4096); });
+        const float c_slab2 = time_k([&]() { k_probe_slab<8><<<(((nb + 7) / 8 + 7) / 8) * 8, 512>>>(buf[si], buf[t], nb, 512); });
+        printf("in = storage %2zu  out = storage %2zu  kernel %.4f ms | library probe (7-pt sweep over the probe grid) %.4f ms  brick copy range %.4f  xcd eighths %.4f  slab 16 MiB %.4f  slab 2 MiB %.4f\n", si, t, ms,
+               probe_ms, c_range, c_xcd8, c_slab, c_slab2);
         fflush(stdout);
       }
     }
