@@ -231,7 +231,14 @@ predrow) # DEV=1 build: cube kernels, box entry point over a registered table --
 shift7)  # 7-point box kernel: the output storage shifted against the input storage (does the DRAM channel / bank alignment of the two streams matter?)
   for A in ${SHIFTS:-0 256 1024 4096 8192 32768 69632 1052672 0}; do run -n 512 -s ${SID:-0} -S -b -v 100 -i ${IT:-100} -r2 2 ${AOPT:--A} $A; done ;;
 place7)  # 7-point box kernel over freshly allocated output storages in ONE process: does the physical placement matter?
-  run -n 512 -s ${SID:-0} -S -b -v 100 -i ${IT:-60} ${TOPT:--T} ${TRIALS:-24} ;;
+  run -n 512 -s ${SID:-0} -S -b -v 100 -i ${IT:-60} ${TOPT:--T} ${TRIALS:-24} ${FOPT:-} ;;
+tune7p)  # DEV=1 build, storages placed (-Q): the 7-point kernel's knobs once more, now that the pair of storages is of the fast kind
+  run -n 512 -s 0 -S -Q -b -v 100 -i 100 -r2 3
+  for L in 0 32000; do run -n 512 -s 0 -S -Q -b -v 100 -i 100 -r2 2 -L $L; done
+  for o in 2 4 8 16; do run -n 512 -s 0 -S -Q -o $o -v 100 -i 100 -r2 2; done
+  run -n 512 -s 0 -S -Q -b -v 100 -i 100 -r2 2 -Z ;;
+rows25)  # star kernels (march, k-paired lists declared) over placed storages: rows per block of the XCD slab order, time and (below) traffic
+  for sid in 4 3; do for o in 8 4 2; do run -n 512 -s $sid -S -Q -o $o -PP -v 100 -i 60 -r2 2; done; done ;;
 reg7)    # 7-point box kernel with / without brk_adjacency_register
   for r in 1 2 3; do run -n 512 -s 0 -S -b -v 0 -i 60; run -n 512 -s 0 -S -b -v 0 -i 60 -R; done ;;
 order7)  # 7-point list form: rows per block of the XCD slab order

@@ -182,7 +182,8 @@ int main(int argc, char **argv) {
   long run = 4, nlev = 2; // -P / -J: entries per run; -P: k-levels per group (-K)
   bool one_alloc = false;
   int trials = 0;
-  bool trial_copy = false;
+  bool trial_copy = false, placed = false, declare_kpaired = false;
+  unsigned trial_flags = 0;
   size_t out_shift = 0;   // -A: the output storage starts this many bytes into its allocation (DRAM channel / bank alignment of out against in)
   std::vector<int> variants = {1, 2, 5};
   for (int a = 1; a < argc; ++a) {
@@ -204,6 +205,9 @@ int main(int argc, char **argv) {
     else if (o == "-R") reg = true;        // brk_adjacency_register: the table is promised immutable
     else if (o == "-Z") zigzag = true;     // list form: every other launch walks each XCD's share of the list backwards (groups of 8 kept)
     else if (o == "-A") out_shift = (size_t)atol(argv[++a]);
+    else if (o == "-PP") kpair = declare_kpaired = true; // -P and the list is DECLARED k-paired (brk_stencil_apply_list_kpaired: the march kernels of the default build)
+    else if (o == "-Q") placed = true; // storages from brk_storage_alloc: the output storage is placed against the input storage
+    else if (o == "-F") trial_flags = (unsigned)atoi(argv[++a]); // -T: the fresh storages come from hipExtMallocWithFlags (1 fine-grained, 3 uncached, 4 physically contiguous)
     else if (o == "-Tc") { trials = atoi(argv[++a]); trial_copy = true; } // the same with a plain brick copy (non-temporal stores) instead of the stencil
     else if (o == "-T") trials = atoi(argv[++a]); // placement trials: the variant list is timed over `trials` freshly allocated output storages (earlier ones stay allocated)
     else if (o == "-A1") { one_alloc = true; out_shift = (size_t)atol(argv[++a]); } // in and out carved out of ONE allocation: out = in + round_up(size, 2 MiB) + shift
@@ -303,6 +307,14 @@ int main(int argc, char **argv) {
     st_out = (double *)(raw + field_2m + out_shift);
     CK(hipMalloc(&st_ref, elems * 8));
     printf("# one allocation %p: out - in = %zu B\n", (void *)raw, field_2m + out_shift);
+  } else if ((decomp || separate) && placed) {
+    void *a = nullptr, *b = nullptr;
+    brk_placement rep;
+    BK(brk_storage_alloc(elems * 8, &a, nullptr));
+    BK(brk_storage_alloc(elems * 8, &b, &rep));
+    st_in = (double *)a, st_out = (double *)b;
+    CK(hipMalloc(&st_ref, elems * 8));
+    printf("# placed: %d candidates, chosen %d, probe sweep %.4f ms (slowest candidate %.4f)\n", rep.candidates, rep.chosen, rep.ms_chosen, rep.ms_worst);
   } else if (decomp || separate) {
     CK(hipMalloc(&st_in, elems * 8));
     char *raw;
@@ -346,7 +358,9 @@ int main(int argc, char **argv) {
     if (boxmode && !decomp) {
       uint32_t SBu = (uint32_t)(N / 8 + 2), tot[3] = {SBu, SBu, SBu}, lo3[3] = {1, 1, 1}, cnt[3] = {SBu - 2, SBu - 2, SBu - 2};
       BK(brk_stencil_apply_box(sid, adj_d, st_in, out, step, 0, tot, lo3, cnt, cp, nullptr));
-    } else if (ids_d)
+    } else if (ids_d && kpair && declare_kpaired)
+      BK(brk_stencil_apply_list_kpaired(sid, adj_d, st_in, out, step, ids_d, nlist, cp, nullptr));
+    else if (ids_d)
       BK(brk_stencil_apply_list(sid, adj_d, st_in, out, step, (rids_d && (launches++ & 1)) ? rids_d : ids_d, nlist, cp, nullptr));
     else
       BK(brk_stencil_apply_range(sid, adj_d, st_in, out, step, first, first + nlist, cp, nullptr));
@@ -410,7 +424,8 @@ int main(int argc, char **argv) {
     std::vector<double *> buf = {st_in, st_out, st_ref};
     for (int t = 0; t < trials; ++t) {
       char *raw;
-      CK(hipMalloc(&raw, elems * 8));
+      if (trial_flags) CK(hipExtMallocWithFlags((void **)&raw, elems * 8, trial_flags));
+      else CK(hipMalloc(&raw, elems * 8));
       buf.push_back((double *)raw);
     }
     auto timed = [&](const double *src, double *dst) {
