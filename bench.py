@@ -797,7 +797,7 @@ def run_weak(args, bl, dev, rank, world):
     for m in ex.plan.msgs:
         if m["is_send"]:
             per_peer[m["peer"]] = per_peer.get(m["peer"], 0) + m["bytes"]
-    res = {"workload": f"weak-{name[:-3] if upd == 2 else name}-{N}", "passes_per_step": S, "conservation_rel_drift": drift, "updates_per_pass": upd, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+    res = {"workload": f"weak-{name[:-3] if upd == 2 else name}-{N}", "storage_placement": stB.placement, "passes_per_step": S, "conservation_rel_drift": drift, "updates_per_pass": upd, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,   # per pass: one read + one write per cell
            "kernel": "%s passes over brick lists of BrickDecomp(%d^3): %d passes (%d sweeps) + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S * upd, S),
            "cart": cart, "overlap": overlap, "exchange": args.exchange, "transport": transport, "transport_fallback_reason": fallback_reason, "exchange_self_check": self_check,
@@ -900,7 +900,7 @@ def run_strong(args, bl, dev, rank, world):
     upd = 2 if name.endswith("_x2") else 1
     cells = float(args.strong_dom) ** 3 * S * upd
     local_cells = float(args.strong_sub) ** 3 * sr.nsub
-    res = {"workload": f"strong-{name}-{args.strong_dom}-{args.strong_sub}", "passes_per_step": S, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
+    res = {"workload": f"strong-{name}-{args.strong_dom}-{args.strong_sub}", "storage_placement": [st.placement for st in sr.storages], "passes_per_step": S, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * local_cells,
            "kernel": "%s sweeps over %d subdomains of %d^3 (+ghost) per rank, one launch per sweep; kernel_ms = step / %d"
                      % (name, sr.nsub, args.strong_sub, S),

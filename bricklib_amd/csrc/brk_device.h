@@ -62,6 +62,8 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
 struct CubeRegular {
   const uint32_t *mask = nullptr;
   uint32_t s1 = 0, s2 = 0;
+  const uint32_t *faces = nullptr; // compact face rows of a registered table (k_face_table): with them and the link bits every wave of a
+                                   // group works out the group's links from scalars -- what the LDS-DMA staged kernel k_cube_dma needs
 };
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *linkmask, const CubeRegular &cubereg = CubeRegular());

@@ -262,6 +262,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   std::lock_guard<std::mutex> adj_lock(g_adj_mutex); // held until the launch below is enqueued (see the lifetime rule above)
   if (id == BRK_27PT_COEFF || id == BRK_MPI125 || id == BRK_MPI7_X2 || id == BRK_7PT_X2) {
     if (int rc = link_mask_locked(adj, &lmask)) return rc; // cube kernels over a registered table: the rows of the list neighbours need not be read
+    if (int rc = face_table_locked(adj, &cubereg.faces)) return rc;
     // measured (profiles/r04_h_predicted_rows.txt, interleaved): 27-point -0.8 ... -1.5 %, fused double 7-point pass -1 %, 125-point +1.7 %
     // (its waves then issue their requests earlier and collide more): the 125-point kernel keeps loading its rows
     if (box_strides && lmask && id != BRK_MPI125) {
@@ -280,7 +281,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st, lmask, cubereg);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = var;
-    if (v == 0 || (v >= 5 && v <= 14)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st, lmask, cubereg);
+    if (v == 0 || (v >= 5 && v <= 15)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st, lmask, cubereg);
     if ((id == BRK_27PT_COEFF && v == 2) || (id == BRK_MPI125 && (v == 2 || v == 4 || v == 8)))
       return launch_cube_wg(id, id == BRK_MPI125 ? v : 8, adj, in, out, step, ids, first, n, cf, st);
   }

@@ -180,7 +180,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     return;
   }
   const bool s7 = name.find("k_s7_wg<") != std::string::npos, swg = name.find("k_star_wg<") != std::string::npos,
-             skp = name.find("k_star_kp<") != std::string::npos || name.find("k_star_km<") != std::string::npos, cd = name.find("k_cube_dense<") != std::string::npos,
+             skp = name.find("k_star_kp<") != std::string::npos || name.find("k_star_km<") != std::string::npos, cd = name.find("k_cube_dense<") != std::string::npos || name.find("k_cube_dma<") != std::string::npos,
              tp = name.find("k_taps<") != std::string::npos;
   if (s7 || swg || skp || cd || tp) {
     const uint32_t *adj = arg<const uint32_t *>(args, 0);
@@ -248,10 +248,16 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     const brklib::Coeffs cf = arg<brklib::Coeffs>(args, 7);
     const std::vector<uint32_t> list = checked_list(adj, in, out, step, ids, first, n);
     if (cd) {
-      const std::vector<long> ta = targs(name, "k_cube_dense");
-      const uint32_t *linkmask = arg<const uint32_t *>(args, 9);
+      const bool dma = name.find("k_cube_dma<") != std::string::npos; // (..., cf, linkmask, faces, cubemask, cs1, cs2): no `diag` argument
+      const std::vector<long> ta = targs(name, dma ? "k_cube_dma" : "k_cube_dense");
+      const uint32_t *linkmask = arg<const uint32_t *>(args, dma ? 8 : 9);
+      if (dma && (!linkmask || !arg<const uint32_t *>(args, 9))) {
+        fprintf(stderr, "hipmock: k_cube_dma launched without the tables of a registered adjacency\n");
+        abort();
+      }
       if (linkmask)
         for (uint32_t b : list) need("link mask", linkmask + 4 * (size_t)(b >> 6), 16);
+      if (dma) check_faces(adj, arg<const uint32_t *>(args, 9), list);
       // box entry point over a registered table: a set bit promises that the row the kernel computes IS the row of the table
       const uint32_t *cubemask = arg<const uint32_t *>(args, 10);
       const uint32_t cs1 = arg<uint32_t>(args, 11), cs2 = arg<uint32_t>(args, 12);

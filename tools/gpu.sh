@@ -239,6 +239,8 @@ tune7p)  # DEV=1 build, storages placed (-Q): the 7-point kernel's knobs once mo
   run -n 512 -s 0 -S -Q -b -v 100 -i 100 -r2 2 -Z ;;
 rows25)  # star kernels (march, k-paired lists declared) over placed storages: rows per block of the XCD slab order, time and (below) traffic
   for sid in 4 3; do for o in 8 4 2; do run -n 512 -s $sid -S -Q -o $o -PP -v 100 -i 60 -r2 2; done; done ;;
+dmacube) # VARIANTS=1 build: cube kernels staged by LDS-DMA (variant 15, k_cube_dma) vs through registers (0), registered table, placed storages, box and list form
+  for sid in 1 5 7; do run -n 512 -s $sid -S -Q -b -v 115,100 -i 40 -r2 4; run -n 512 -s $sid -S -Q -o 8 -v 115,100 -i 40 -r2 3; done ;;
 reg7)    # 7-point box kernel with / without brk_adjacency_register
   for r in 1 2 3; do run -n 512 -s 0 -S -b -v 0 -i 60; run -n 512 -s 0 -S -b -v 0 -i 60 -R; done ;;
 order7)  # 7-point list form: rows per block of the XCD slab order
