@@ -422,6 +422,16 @@ int main(int argc, char **argv) {
     // sweep timed from storage A into storage B for A = the original input and two of the fresh ones
     BK(brk_adjacency_register(adj_d, nbricks));
     std::vector<double *> buf = {st_in, st_out, st_ref};
+    if (trial_flags & 8u) { // -F 12 / -F 8: ONE allocation (physically contiguous with bit 4) carved into `trials` storages, 1 GiB + 128 MiB apart
+      const size_t pitch = ((size_t)1 << 30) + ((size_t)128 << 20);
+      if (elems * 8 > pitch) { fprintf(stderr, "storage larger than the carving pitch\n"); return 2; }
+      char *raw;
+      if (trial_flags & 4u) CK(hipExtMallocWithFlags((void **)&raw, pitch * trials, 4u));
+      else CK(hipMalloc(&raw, pitch * trials));
+      buf.clear();
+      for (int t = 0; t < trials; ++t) buf.push_back((double *)(raw + pitch * t));
+      printf("# one allocation of %.1f GiB at %p%s, storages every %.3f GiB\n", pitch * trials / 1073741824.0, (void *)raw, (trial_flags & 4u) ? " (hipDeviceMallocContiguous)" : "", pitch / 1073741824.0);
+    } else
     for (int t = 0; t < trials; ++t) {
       char *raw;
       if (trial_flags) CK(hipExtMallocWithFlags((void **)&raw, elems * 8, trial_flags));
