@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 import os
+import sys
 
 from ._lib import Placement, check, l3, lib
 
@@ -94,7 +95,7 @@ class _PlacedMemory:
 
     def __del__(self):
         ptr, self.ptr = getattr(self, "ptr", None), None
-        if ptr:
+        if ptr and not sys.is_finalizing():      # at interpreter exit the process teardown returns the memory; no HIP calls from there
             try:
                 with torch.cuda.device(self.device):
                     lib.brk_storage_free(C.c_void_p(ptr))
