@@ -287,7 +287,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   // the output-side 125-point form reads everything from LDS (no register copy of the brick's own column): the brick and its
   // k-faces are moved in 16-byte lanes too -- lane l of instruction q takes elements 2(l%32), +1 of plane 2q + l/32
   constexpr bool KF16 = KIND == kCube125 && PIPE == 5; // both planes of a k-face go to LDS: one full-wave instruction per side
-  constexpr bool LD16 = KF16 || KIND == kCube27; // (the diamond at 128 VGPRs spills with the 16-byte staging registers: 0.53 vs 0.43 ms)
+  // The diamond as well since round 4, but only with the plane loop WITHOUT read-ahead (PIPE 0: 116 VGPRs): with the read-ahead the
+  // kernel sits at its 128-register bound, hipcc spills two gathered values and waits for vmcnt(0) in the middle of the fetch phase to
+  // store them (0.545 vs 0.430 ms).  8 instead of 15 vector memory instructions per wave: 0.427-0.430 vs 0.430-0.435 ms.
+  constexpr bool LD16 = KF16 || KIND == kCube27 || (KIND == kDiamond25 && PIPE == 0);
   // 27-point: ONE plane per side goes to LDS (plane 7 below -> level R-1, plane 0 above -> level R+8): both sides in one
   // instruction, half a wave each
   constexpr bool KF16H = LD16 && !KF16;
@@ -811,7 +814,7 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
   }
   const uint32_t wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
   bool done = true;
-  if (x2 && variant == 2) BRK_CD(kDiamond25, 4, 4, 0, wgs4, g_pad_lds);                       // plane loop without read-ahead
+  if (x2 && variant == 2) BRK_CD(kDiamond25, 4, 4, 1, wgs4, g_pad_lds);                       // plane loop with read-ahead, 8-byte staging (the default until round 4)
   else if (stencil_id == BRK_27PT_COEFF && variant == 5) BRK_CD(kCube27, 8, 4, 1, wgs8, g_pad_lds);
   else if (stencil_id == BRK_MPI125 && variant == 6) BRK_CD(kCube125, 4, 2, 1, wgs4, g_pad_lds);
   else if (stencil_id == BRK_MPI125 && variant == 7) BRK_CD(kCube125, 8, 2, 1, wgs8, g_pad_lds);
@@ -826,7 +829,7 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
   }
 #endif
   (void)variant;
-  if (x2) BRK_CD(kDiamond25, 4, 4, 1, wgs4, g_pad_lds);
+  if (x2) BRK_CD(kDiamond25, 4, 4, 0, wgs4, g_pad_lds); // plane loop without read-ahead, 16-byte staging (see LD16)
   else if (stencil_id == BRK_27PT_COEFF) BRK_CD(kCube27, 4, 5, 1, wgs4, g_pad_lds);
   else BRK_CD(kCube125, 4, 3, 5, wgs4, g_pad_lds); // output-side j-shift: 60 + 40 LDS reads per lane, the shift through a wave-private slot
 #undef BRK_CD
