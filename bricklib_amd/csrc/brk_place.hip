@@ -14,6 +14,7 @@
 // different kinds: fast; clean to 0.3 %); the search stops once both rates have been seen among at least six candidates.
 // 50-150 ms per storage, at setup.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -32,8 +33,12 @@ std::mutex g_place_mutex;
 std::vector<Placed> g_placed; // live storages handed out by brk_storage_alloc, in allocation order
 
 constexpr size_t kMinPlaced = (size_t)64 << 20;      // smaller storages are not worth a measurement
-constexpr size_t kCandidateBudget = (size_t)28 << 30; // memory held by candidates while one storage is placed
-constexpr int kMinCandidates = 6, kMaxCandidates = 24; // runs of up to 11 consecutive allocations of one kind were seen
+constexpr size_t kCandidateBudget = (size_t)28 << 30; // memory held by back-to-back candidates while one storage is placed
+constexpr int kMinCandidates = 6, kMaxCandidates = 24; // runs of up to 11 consecutive allocations of one kind are common
+// ... and runs of 25 x 1.2 GB and a 45-GiB allocation of one kind have been seen: when the back-to-back candidates show one rate only,
+// SPACERS (allocated, never touched, freed with the rejected candidates) move the next candidates further on
+constexpr size_t kSpacerGiB[] = {4, 8, 16, 16, 16};
+constexpr size_t kHeldBudget = (size_t)72 << 30; // everything held at once while one storage is placed, and never more than a third of what is free
 constexpr double kBothKindsSeen = 0.985;               // the two sweep rates are 2.5-3 % apart, repeats of one pair within 0.3 %
 constexpr uint32_t kMaxProbeEdge = 82;                 // bricks per axis of the probe grid: at most 82^3 x 4 KiB = 2.3 GB swept per launch
 
@@ -128,33 +133,56 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
     for (const Placed &p : partners) probe_bytes = std::min(probe_bytes, p.bytes);
     ProbeGrid grid;
     if (int rc0 = make_probe_grid(probe_bytes, grid)) return rc0;
-    std::vector<void *> cands;
+    std::vector<void *> cands, spacers;
     std::vector<double> score;
     int best = -1;
     double worst = 0.0;
     int rc = BRK_OK;
-    for (int t = 0; t < ncand; ++t) {
+    size_t held = 0;
+    const size_t held_cap = std::min(kHeldBudget, free_b / 3);
+    // one more candidate: allocate, time the probe sweep from every partner into it; false when there is no room for it
+    auto try_candidate = [&]() {
       void *c = nullptr;
-      if (hipMalloc(&c, bytes) != hipSuccess) {
+      if (held + bytes > std::max(held_cap, bytes) || hipMalloc(&c, bytes) != hipSuccess) {
         (void)hipGetLastError(); // out of room for further candidates: settle for what was seen
-        break;
+        return false;
       }
       cands.push_back(c);
+      held += bytes;
       double sc = 0.0; // milliseconds per probe sweep, slowest partner
       for (const Placed &p : partners) {
         double ms = 0.0;
         rc = probe_locked(grid, p.p, c, nullptr, &ms);
-        if (rc) break;
+        if (rc) return false;
         sc = std::max(sc, ms);
       }
-      if (rc) break;
       score.push_back(sc);
       if (best < 0 || sc < score[best]) best = (int)score.size() - 1;
       worst = std::max(worst, sc);
-      // both rates have been seen and a few candidates of the fast kind compared: done.  Otherwise keep allocating -- runs of ten
-      // consecutive allocations of one kind occur
-      if ((int)score.size() >= kMinCandidates && score[best] <= kBothKindsSeen * worst) break;
+      return true;
+    };
+    // both rates have been seen and a few candidates compared: done
+    auto contrast = [&]() { return (int)score.size() >= std::min(kMinCandidates, ncand) && score[best] <= kBothKindsSeen * worst; };
+    const bool force_spacers = std::getenv("BRK_PLACEMENT_TEST_SPACERS") != nullptr; // tests: take the spacer path whatever the candidates say
+    for (int t = 0; t < ncand && rc == BRK_OK; ++t) {
+      if (!try_candidate()) break;
+      if (contrast() && !force_spacers) break;
     }
+    if (rc == BRK_OK && best >= 0 && (!contrast() || force_spacers)) {
+      for (size_t gib : kSpacerGiB) {
+        const size_t sp = gib << 30;
+        void *spacer = nullptr;
+        if (held + sp + 2 * bytes > held_cap || hipMalloc(&spacer, sp) != hipSuccess) {
+          (void)hipGetLastError();
+          break;
+        }
+        spacers.push_back(spacer);
+        held += sp;
+        bool more = try_candidate() && try_candidate();
+        if (!more || rc || (contrast() && !force_spacers)) break;
+      }
+    }
+    for (void *sp : spacers) (void)hipFree(sp);
     if (rc || best < 0) {
       for (void *c : cands) (void)hipFree(c);
       if (rc) return rc;
@@ -165,6 +193,8 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
       if ((int)q != best) (void)hipFree(cands[q]);
     if (report) {
       report->candidates = (int)score.size();
+      report->spacer_gib = 0;
+      for (size_t q = 0; q < spacers.size(); ++q) report->spacer_gib += (int)kSpacerGiB[q];
       report->chosen = best;
       report->probe_bricks = (int)((grid.edge - 2) * (grid.edge - 2) * (grid.edge - 2));
       report->ms_chosen = score[best];

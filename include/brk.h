@@ -174,7 +174,9 @@ int brk_link_copy(const brk_link *links_dev, uint32_t n, uint64_t max_bytes, brk
  * storages lie in regions of the same kind its read and write streams meet in the same DRAM banks (7-point, 512^3: 0.371 ms
  * against 0.361 ms; profiles/r04_g_*).  brk_storage_alloc is hipMalloc + a measurement: storages of at least 64 MiB are
  * placed where a 7-point sweep from the (two) storages allocated before them into the new one runs fastest: 6 to 24
- * candidate allocations (at most 28 GiB of them) are measured, all but the best are freed before the call returns.
+ * candidate allocations (at most 28 GiB of them) are measured -- when they all run at one rate, up to 60 GiB of untouched
+ * spacer allocations move further candidates on (never more than a third of the free memory is held) --, all but the best
+ * are freed before the call returns.
  * Synchronous, 50-150 ms per storage; meant for set-up.  Memory from brk_storage_alloc is released with brk_storage_free.
  * brk_placement_probe is the measurement itself: milliseconds per BRK_MPI7 sweep (brk_stencil_apply_box) from a into b over
  * the largest cubic brick grid (at most 82^3) that `bytes` hold, on stream s; b is OVERWRITTEN.                         */
@@ -182,6 +184,7 @@ typedef struct {
   int candidates;   /* allocations measured (0: the storage was too small or had no partner, plain hipMalloc) */
   int chosen;       /* index of the one kept */
   int probe_bricks; /* bricks swept per probe launch */
+  int spacer_gib;   /* GiB of spacer allocations it took to reach candidates of the other kind (0: back-to-back candidates sufficed) */
   double ms_chosen; /* probe sweep from the slowest partner into the chosen candidate */
   double ms_worst;  /* ... into the slowest candidate seen */
 } brk_placement;

@@ -81,6 +81,29 @@ def test_placed_memory_is_returned_with_the_tensor(dev, monkeypatch):
     assert free0 - free3 <= (32 << 20)
 
 
+def test_spacer_path_of_the_allocator(dev, monkeypatch):
+    """when every back-to-back candidate runs at one rate the allocator moves on behind untouched spacer allocations; the test forces
+    that path (BRK_PLACEMENT_TEST_SPACERS) and holds that it works and that everything but the chosen storage is given back"""
+    monkeypatch.setenv("BRK_PLACEMENT", "1")
+    monkeypatch.setenv("BRK_PLACEMENT_TEST_SPACERS", "1")
+    gc.collect()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    nbytes = 96 << 20
+    a = bl.BrickStorage.allocate(nbytes // 8 // 512, 512, dev)
+    b = bl.BrickStorage.allocate(nbytes // 8 // 512, 512, dev)
+    assert b.placement["spacer_gib"] >= 4 and b.placement["candidates"] >= 8
+    assert 0 <= b.placement["chosen"] < b.placement["candidates"]
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free1 <= 2 * nbytes + (64 << 20)       # spacers and rejected candidates are gone
+    a.dat.fill_(1.0)
+    b.dat.copy_(a.dat)
+    assert float(b.dat.sum()) == a.dat.numel()
+    del a, b
+    gc.collect()
+
+
 def test_placement_probe_and_c_abi_allocator(dev):
     nbytes = 128 << 20
     a, b = C.c_void_p(), C.c_void_p()
