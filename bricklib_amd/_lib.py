@@ -23,7 +23,7 @@ class Region(C.Structure):
 
 class Placement(C.Structure):
     """brk_placement: what brk_storage_alloc measured while it placed a storage"""
-    _fields_ = [("candidates", C.c_int), ("chosen", C.c_int), ("probe_bricks", C.c_int), ("spacer_gib", C.c_int), ("ms_chosen", C.c_double), ("ms_worst", C.c_double)]
+    _fields_ = [("candidates", C.c_int), ("chosen", C.c_int), ("probe_bricks", C.c_int), ("spacer_gib", C.c_int), ("ms_chosen", C.c_double), ("ms_worst", C.c_double), ("ms_same_allocation", C.c_double)]
 
 
 class Link(C.Structure):

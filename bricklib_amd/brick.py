@@ -90,7 +90,8 @@ class _PlacedMemory:
             check(lib.brk_storage_alloc(self.nelem * 8, C.byref(ptr), C.byref(rep)))
         self.ptr = ptr.value
         self.report = {"candidates": rep.candidates, "chosen": rep.chosen, "probe_bricks": rep.probe_bricks, "spacer_gib": rep.spacer_gib,
-                       "probe_sweep_ms_chosen": rep.ms_chosen, "probe_sweep_ms_worst": rep.ms_worst}
+                       "probe_sweep_ms_chosen": rep.ms_chosen, "probe_sweep_ms_worst": rep.ms_worst,
+                       "probe_sweep_ms_same_allocation": rep.ms_same_allocation}
         self.__cuda_array_interface__ = {"shape": (self.nelem,), "typestr": "<f8", "data": (self.ptr, False), "version": 2}
 
     def __del__(self):

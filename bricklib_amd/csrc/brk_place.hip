@@ -11,8 +11,9 @@
 // the allocator of brick storages MEASURES: candidate allocations are made (6 to 24, all held until the choice is made so that each
 // lies somewhere else), a 7-point sweep from the storages allocated before into each candidate is timed, the candidate with the
 // fastest sweep is kept and the others are freed.  For the sweep the storages of a process fall into two kinds (same kind: slow,
-// different kinds: fast; clean to 0.3 %); the search stops once both rates have been seen among at least six candidates.
-// 50-150 ms per storage, at setup.
+// different kinds: fast; clean to 0.3 %); the search stops once both rates have been seen among at least six candidates -- the slow
+// rate of the device is measured first (a sweep between the two halves of ONE allocation) -- and moves on behind untouched spacer
+// allocations when every back-to-back candidate is of the partner's kind.  50-150 ms per storage, at setup.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -161,8 +162,23 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
       worst = std::max(worst, sc);
       return true;
     };
+    // What the SLOW rate is on this device, for this probe grid: the same sweep between the two halves of ONE allocation (an allocation is
+    // of one kind; should it straddle two, the reference reads fast and the search below merely runs longer).  With it a run of
+    // candidates that are all fast is recognised as such (no spacers), and so is a run that is all slow.
+    double slow_ref = 0.0;
+    if (2 * bytes <= held_cap) {
+      void *both = nullptr;
+      if (hipMalloc(&both, 2 * bytes) == hipSuccess) {
+        rc = probe_locked(grid, both, static_cast<char *>(both) + bytes, nullptr, &slow_ref);
+        (void)hipFree(both);
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     // both rates have been seen and a few candidates compared: done
-    auto contrast = [&]() { return (int)score.size() >= std::min(kMinCandidates, ncand) && score[best] <= kBothKindsSeen * worst; };
+    auto contrast = [&]() {
+      return (int)score.size() >= std::min(kMinCandidates, ncand) && score[best] <= kBothKindsSeen * std::max(worst, slow_ref);
+    };
     const bool force_spacers = std::getenv("BRK_PLACEMENT_TEST_SPACERS") != nullptr; // tests: take the spacer path whatever the candidates say
     for (int t = 0; t < ncand && rc == BRK_OK; ++t) {
       if (!try_candidate()) break;
@@ -199,6 +215,7 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
       report->probe_bricks = (int)((grid.edge - 2) * (grid.edge - 2) * (grid.edge - 2));
       report->ms_chosen = score[best];
       report->ms_worst = worst;
+      report->ms_same_allocation = slow_ref;
     }
   }
   g_placed.push_back({chosen, bytes, device});

@@ -187,6 +187,7 @@ typedef struct {
   int spacer_gib;   /* GiB of spacer allocations it took to reach candidates of the other kind (0: back-to-back candidates sufficed) */
   double ms_chosen; /* probe sweep from the slowest partner into the chosen candidate */
   double ms_worst;  /* ... into the slowest candidate seen */
+  double ms_same_allocation; /* the same sweep between the two halves of one allocation: the slow rate of this device (0: not measured) */
 } brk_placement;
 int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *report /* may be NULL */);
 int brk_storage_free(void *p_dev);
