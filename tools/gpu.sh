@@ -124,7 +124,7 @@ tapmc)   # how busy is the vector memory path (TA / TCP / TD) in each default ke
                 "TCP_GATE_EN1_sum TCP_GATE_EN2_sum" "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" \
                 "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum" "TCP_TAGRAM0_REQ_sum TCP_TAGRAM1_REQ_sum" "TD_TD_BUSY_sum TD_TC_STALL_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
       i=$((i + 1)); rm -rf gpurun_out/tapmc_${sid}_$i
-      timeout -k 10 200 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/tapmc_${sid}_$i -- tools/kbench -n 512 -s $sid -S -o 8 -v 0 -i 10 > /dev/null 2>&1
+      timeout -k 10 200 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d gpurun_out/tapmc_${sid}_$i -- tools/kbench -n 512 -s $sid -S -Q -b -v 100 -i 10 > /dev/null 2>&1
     done
     python3 - $sid <<'PY'
 import csv, glob, sys, collections
@@ -134,7 +134,7 @@ name = None
 for f in glob.glob(f"gpurun_out/tapmc_{sid}_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if ("k_s7_wg" in k or "k_star_wg" in k or "k_cube_dense" in k):
+        if (("k_s7_wg<0" in k and sid == "0") or "k_star_wg" in k or "k_star_km" in k or "k_cube_dense" in k):
             name = k.split("(")[0][-40:]
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(f"stencil {sid}: {name}")
