@@ -166,10 +166,11 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
     // of one kind; should it straddle two, the reference reads fast and the search below merely runs longer).  With it a run of
     // candidates that are all fast is recognised as such (no spacers), and so is a run that is all slow.
     double slow_ref = 0.0;
-    if (2 * bytes <= held_cap) {
+    const size_t half = (bytes + 4095) / 4096 * 4096; // the second half starts on a brick boundary whatever `bytes` is
+    if (2 * half <= held_cap) {
       void *both = nullptr;
-      if (hipMalloc(&both, 2 * bytes) == hipSuccess) {
-        rc = probe_locked(grid, both, static_cast<char *>(both) + bytes, nullptr, &slow_ref);
+      if (hipMalloc(&both, 2 * half) == hipSuccess) {
+        rc = probe_locked(grid, both, static_cast<char *>(both) + half, nullptr, &slow_ref);
         (void)hipFree(both);
       } else {
         (void)hipGetLastError();

@@ -205,7 +205,7 @@ static int placement() {
   REQ(brk_storage_alloc(big, &a, &rep) == BRK_OK && a && rep.candidates == 0); // nothing to place it against yet
   REQ(brk_storage_alloc(big + 4096, &b, &rep) == BRK_OK && b && rep.candidates >= 2 && rep.chosen >= 0 && rep.chosen < rep.candidates &&
       rep.ms_chosen > 0 && rep.ms_chosen <= rep.ms_worst && rep.probe_bricks == 23 * 23 * 23); // 65 MiB hold 25^3 bricks
-  REQ(brk_storage_alloc(big - 4096, &c, nullptr) == BRK_OK && c);
+  REQ(brk_storage_alloc(big - 4096 + 24, &c, nullptr) == BRK_OK && c); // a size that is no multiple of a brick, nor of 16 bytes
   REQ(hipmock_live_allocations() == live0 + 4); // the rejected candidates are gone
   double ms = 0.0;
   REQ(brk_placement_probe(a, b, big, nullptr, &ms) == BRK_OK && ms > 0.0);
