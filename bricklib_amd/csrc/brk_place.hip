@@ -123,7 +123,8 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
   for (size_t q = g_placed.size(); q-- > 0 && partners.size() < 2;)
     if (g_placed[q].device == device && g_placed[q].bytes >= kMinPlaced) partners.push_back(g_placed[q]);
   void *chosen = nullptr;
-  if (bytes < kMinPlaced || partners.empty()) {
+  const char *off = std::getenv("BRK_PLACEMENT"); // BRK_PLACEMENT=0: every storage is a plain hipMalloc (A/B runs)
+  if (bytes < kMinPlaced || partners.empty() || (off && off[0] == '0' && off[1] == 0)) {
     HIP_TRY(hipMalloc(&chosen, bytes));
   } else {
     size_t free_b = 0, total_b = 0;

@@ -178,6 +178,7 @@ int brk_link_copy(const brk_link *links_dev, uint32_t n, uint64_t max_bytes, brk
  * spacer allocations move further candidates on (never more than a third of the free memory is held) --, all but the best
  * are freed before the call returns.
  * Synchronous, 50-150 ms per storage; meant for set-up.  Memory from brk_storage_alloc is released with brk_storage_free.
+ * With BRK_PLACEMENT=0 in the environment every storage is a plain hipMalloc (for A/B runs).
  * brk_placement_probe is the measurement itself: milliseconds per BRK_MPI7 sweep (brk_stencil_apply_box) from a into b over
  * the largest cubic brick grid (at most 82^3) that `bytes` hold, on stream s; b is OVERWRITTEN.                         */
 typedef struct {
