@@ -118,9 +118,11 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(g_place_mutex);
-  // the storages a sweep will pair this one with: the (at most two) most recent live ones of this device that are worth measuring
+  // the storage a sweep will pair this one with: the most recent live one of this device that is worth measuring.  ONE partner: there are
+  // two kinds, so a chain of storages placed each against its predecessor alternates A B A B -- what ping-pong pairs and the three
+  // rotating storages of the strong driver (0 -> 1 -> 2 -> 1 -> 0) need; against two partners of different kinds nothing can be gained
   std::vector<Placed> partners;
-  for (size_t q = g_placed.size(); q-- > 0 && partners.size() < 2;)
+  for (size_t q = g_placed.size(); q-- > 0 && partners.size() < 1;)
     if (g_placed[q].device == device && g_placed[q].bytes >= kMinPlaced) partners.push_back(g_placed[q]);
   void *chosen = nullptr;
   const char *off = std::getenv("BRK_PLACEMENT"); // BRK_PLACEMENT=0: every storage is a plain hipMalloc (A/B runs)

@@ -173,7 +173,7 @@ int brk_link_copy(const brk_link *links_dev, uint32_t n, uint64_t max_bytes, brk
  * 2.7 % of a bandwidth-bound sweep to chance: HBM is made of regions of about 8 GiB, and when a sweep's input and output
  * storages lie in regions of the same kind its read and write streams meet in the same DRAM banks (7-point, 512^3: 0.371 ms
  * against 0.361 ms; profiles/r04_g_*).  brk_storage_alloc is hipMalloc + a measurement: storages of at least 64 MiB are
- * placed where a 7-point sweep from the (two) storages allocated before them into the new one runs fastest: 6 to 24
+ * placed where a 7-point sweep from the storage allocated before them into the new one runs fastest: 6 to 24
  * candidate allocations (at most 28 GiB of them) are measured -- when they all run at one rate, up to 60 GiB of untouched
  * spacer allocations move further candidates on (never more than a third of the free memory is held) --, all but the best
  * are freed before the call returns.
