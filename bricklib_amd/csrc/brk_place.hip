@@ -9,7 +9,7 @@
 // rounds' numbers.
 // The reference allocates a storage wherever the allocator puts it (include/brick.h:68-75, include/brick-gpu.h:80-99); here
 // the allocator of brick storages MEASURES: candidate allocations are made (6 to 24, all held until the choice is made so that each
-// lies somewhere else), a 7-point sweep from the storages allocated before into each candidate is timed, the candidate with the
+// lies somewhere else), a 7-point sweep from the storage allocated before into each candidate is timed, the candidate with the
 // fastest sweep is kept and the others are freed.  For the sweep the storages of a process fall into two kinds (same kind: slow,
 // different kinds: fast; clean to 0.3 %); the search stops once both rates have been seen among at least six candidates -- the slow
 // rate of the device is measured first (a sweep between the two halves of ONE allocation) -- and moves on behind untouched spacer

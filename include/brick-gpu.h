@@ -89,7 +89,7 @@ struct brkSweepTurn {
 };
 
 // new BrickStorage on the destination side holding a copy of the data.  The device side comes from brk_storage_alloc (brk.h): the
-// storage is PLACED in HBM where streams between it and the storages moved before it run fastest (a sweep between two storages in
+// storage is PLACED in HBM where streams between it and the storage moved before it run fastest (a sweep between two storages in
 // DRAM regions of the same kind loses 3 %), which the reference's one-cudaMalloc-per-storage leaves to chance.
 inline BrickStorage movBrickStorage(BrickStorage &bStorage, gpuMemcpyKind kind) {
   assert(kind == gpuMemcpyHostToDevice || kind == gpuMemcpyDeviceToHost);
