@@ -1,5 +1,6 @@
-"""Development script: the rate of a streaming copy (brk_placement_probe) from one storage into each of N freshly allocated ones,
-and between all pairs of the first few -- the picture behind brk_storage_alloc (bricklib_amd/csrc/brk_place.hip).
+"""Development script: brk_placement_probe (today the 7-point sweep over a probe grid; when profiles/r04_g_placement_copy_matrix.txt was
+made it was a linear streaming copy) from one storage into each of N freshly allocated ones, and between all pairs of the first few --
+the picture behind brk_storage_alloc (bricklib_amd/csrc/brk_place.hip).
     python tools/place_probe.py [N] [GiB per storage]"""
 import ctypes as C
 import os
@@ -23,7 +24,7 @@ def probe(a, b):
     return ms.value * (1 << 30) / nbytes
 
 
-print(f"# {n} storages of {nbytes / (1 << 30):.4f} GiB; ms per GiB of a streaming copy row -> column")
+print(f"# {n} storages of {nbytes / (1 << 30):.4f} GiB; probe time (ms, scaled to 1 GiB) row -> column")
 m = min(n, 12)
 print("      " + " ".join(f"{j:6d}" for j in range(m)))
 for i in range(m):
