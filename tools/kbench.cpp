@@ -158,6 +158,26 @@ __global__ __launch_bounds__(256) void k_stream2_persist(const double *in, doubl
   }
 }
 
+// what kind of interaction is the placement effect?  two read streams / two write streams over the same pair of storages
+__global__ __launch_bounds__(256) void k_read2(const double *a, const double *b, double *c, uint32_t nb) {
+  uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= nb) return;
+  int lane = threadIdx.x & 63;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += a[(size_t)w * 512 + k * 64 + lane] + b[(size_t)w * 512 + k * 64 + lane];
+  if (s == 1.2345e300) c[w] = s; // never true: the loads stay
+}
+__global__ __launch_bounds__(256) void k_write2(double *a, double *b, uint32_t nb) {
+  uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= nb) return;
+  int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    __builtin_nontemporal_store((double)lane, &a[(size_t)w * 512 + k * 64 + lane]);
+    __builtin_nontemporal_store((double)k, &b[(size_t)w * 512 + k * 64 + lane]);
+  }
+}
 // candidate placement probes (development): brick copy in the sweep's shape -- planes of PB bricks walked in order, XCD x (= blockIdx & 7)
 // takes the x-th eighth of every plane, one wave per brick, NW waves per workgroup, non-temporal stores
 template <int NW>
@@ -478,10 +498,14 @@ int main(int argc, char **argv) {
           return m2 / 6;
         };
         const uint32_t nb = nbricks;
+        const float c_rr = time_k([&]() { k_read2<<<(nb + 3) / 4, 256>>>(buf[si], buf[t], st_ref, nb); });
+        const float c_ww = trial_copy ? time_k([&]() { k_write2<<<(nb + 3) / 4, 256>>>(buf[0 == si ? 1 : 0], buf[t], nb); }) : 0.f; // -Tc: also two write streams (destroys storage 0/1: run last)
         const float c_range = time_k([&]() { k_stream2_range_nt<0><<<(nb + 3) / 4, 256>>>(buf[si], buf[t], 512, 0, nb); });
         const float c_xcd8 = time_k([&]() { k_stream2_xcd_nt<8, 1><<<(((nb + 7) / 8 + 7) / 8) * 8, 512>>>(buf[si], buf[t], 512, 0, nb); });
         const float c_slab = time_k([&]() { k_probe_slab<8><<<(((nb + 7) / 8 + 7) / 8) * 8, 512>>>(buf[si], buf[t], nb, 4096); });
         const float c_slab2 = time_k([&]() { k_probe_slab<8><<<(((nb + 7) / 8 + 7) / 8) * 8, 512>>>(buf[si], buf[t], nb, 512); });
+        printf("   two read streams over the pair %.4f ms%s\n", c_rr, trial_copy ? "" : "");
+        if (trial_copy) printf("   two write streams (storage %d and storage %zu) %.4f ms\n", 0 == si ? 1 : 0, t, c_ww);
         printf("in = storage %2zu  out = storage %2zu  kernel %.4f ms | library probe (7-pt sweep over the probe grid) %.4f ms  brick copy range %.4f  xcd eighths %.4f  slab 16 MiB %.4f  slab 2 MiB %.4f\n", si, t, ms,
                probe_ms, c_range, c_xcd8, c_slab, c_slab2);
         fflush(stdout);
