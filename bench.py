@@ -426,7 +426,8 @@ def run_single(args, bl, dev):
            # what BrickStorage.allocate measured when it placed the output storage against the input storage (brk_storage_alloc, include/brk.h)
            "storage_placement": sto.placement, "sweep_direction": "alternating" if zigzag else "one way", "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": kern_ms, "alg_bytes_per_launch": BYTES_PER_UPDATE * cells,
-           "kernel": "%s over %d bricks" % ("k_s7_wg<8 waves>" if name in ("7pt", "mpi7pt") else ("k_star_wg" if name in ("mpi13pt", "mpi25pt") else "k_cube_dense"), ids.size)}
+           # the name the launcher recorded for the last stencil launch of this thread (brk_last_kernel, ABI 1008): what actually ran
+           "kernel": "%s over %d bricks" % (bl.last_kernel(), ids.size)}
     extra["timing"] = {"protocol": "%s%d warm-up steps, then the median of %d windows of %d launches, each between two device synchronisations"
                                    % ("the steady-state phase first; " if args.steady_seconds > 0 else "", W, len(wins), K),
                        "window_ms_per_step": [w / K * 1e3 for w, _ in wins], "window_kernel_ms": [k for _, k in wins]}
@@ -724,7 +725,7 @@ def run_weak(args, bl, dev, rank, world):
         schedule, deep_depth = min(cost, key=cost.get)
     overlap = schedule != "plain"
     state = {}
-    kp = name == "mpi25pt"     # the radius-4 star sweeps k-paired lists (two bricks per wave, brk_stencil_apply_list_kpaired)
+    kp = name in ("mpi13pt", "mpi25pt")     # the stars sweep k-paired lists (two bricks per wave, brk_stencil_apply_list_kpaired: 25-point -12 %, 13-point -1.9 %)
     if schedule == "deep":
         lists = TrapezoidLists(d, S, dev, kpair=kp)
         whole = SweepLists(d, dev, kpair=kp)
@@ -902,8 +903,9 @@ def run_strong(args, bl, dev, rank, world):
     local_cells = float(args.strong_sub) ** 3 * sr.nsub
     res = {"workload": f"strong-{name}-{args.strong_dom}-{args.strong_sub}", "storage_placement": [st.placement for st in sr.storages], "passes_per_step": S, "wall": wall, "K": K, "W": W, "cells_per_step": cells,
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * local_cells,
-           "kernel": "%s sweeps over %d subdomains of %d^3 (+ghost) per rank, one launch per sweep; kernel_ms = step / %d"
-                     % (name, sr.nsub, args.strong_sub, S),
+           "kernel": "%s: %s sweeps over %d subdomains of %d^3 (+ghost) per rank, one launch per sweep; kernel_ms = step / %d"
+                     % (bl.last_kernel(), name, sr.nsub, args.strong_sub, S),
+           "sweep_lists": "k-paired (two bricks per wave)" if sr.swept_kpaired else "tiled",
            "scaling": "strong", "updates_per_pass": upd, "conservation_rel_drift": drift, "cells_per_gpu": int(local_cells), "subdomains_per_rank": sr.nsub, "remote_bytes_per_rank": sr.bytes_remote,
            # ghost runs between two subdomains of one rank: reached through the adjacency table ("aliased": neither copied nor swept)
            # or copied by device links as in the reference ("copied"); bricks per sweep over subdomains + ghost rings vs subdomain bricks

@@ -140,6 +140,9 @@ def _load():
     L.brk_comm_library.argtypes = []
     L.brk_adjacency_register.argtypes = [vp, C.c_uint32]
     L.brk_adjacency_release.argtypes = [vp]
+    L.brk_finalize.argtypes = []
+    L.brk_last_kernel.restype = C.c_char_p
+    L.brk_last_kernel.argtypes = []
     return L
 
 
@@ -160,7 +163,7 @@ ABI_SYMBOLS = [
     "brk_exchange_begin", "brk_exchange_transport", "brk_exchange_end", "brk_exchange_run", "brk_exchange_loopback",
     "brk_exchange_view_buffer", "brk_exchange", "brk_comm_unique_id", "brk_comm_init_rank", "brk_comm_destroy", "brk_comm_rank", "brk_comm_library",
     "brk_adjacency_register", "brk_adjacency_release", "brk_decomp_build_order", "brk_skin3d_order",
-    "brk_storage_alloc", "brk_storage_free", "brk_placement_probe",
+    "brk_storage_alloc", "brk_storage_free", "brk_placement_probe", "brk_finalize", "brk_last_kernel",
 ]
 
 

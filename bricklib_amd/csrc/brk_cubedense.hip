@@ -1,6 +1,6 @@
 // brk_cubedense.hip -- cube stencils (27- and 125-point) on dense, bank-conflict-free LDS tiles.
 //
-// The padded (8+2R)^3 tile of brk_cubewg.hip has a row pitch of 10/12 doubles: every ds_read_b64 of the accumulation
+// The padded (8+2R)^3 tile of brk_cubewg_variants.hip has a row pitch of 10/12 doubles: every ds_read_b64 of the accumulation
 // loop is 2-way bank conflicted (a 32-lane half touches rows 4 pitches apart; measured: 50 % of the LDS cycles of the
 // 125-point kernel are conflict cycles, profiles/r01_c_pmc_mpi125pt_512.txt) and the tile costs 8 / 13.8 KiB per wave.
 //
@@ -160,56 +160,6 @@ constexpr DenseExtra<KIND> make_dense_extra() {
   return t;
 }
 
-#ifdef BRK_VARIANTS
-// ---- LDS-DMA staging (round 4, k_cube_dma; MEASURED SLOWER, development builds only: profiles/r04_j_lds_dma_staging.txt): a tile is ELEMS * 8 contiguous bytes, so ceil(ELEMS / 128) instructions of 1 KiB
-// (global_load_lds_dwordx4: 16 bytes per lane, the LDS side contiguous, the global side a per-lane address) fill ALL of it -- own
-// rows, k- and j-faces and the kj-edge rows -- without staging registers and without ds_write.  One descriptor per (instruction,
-// lane): where the 16 bytes that belong at that LDS position come from: adjacency slot << 16 | element offset inside that brick << 21.
-// Rows the diamond never reads are pointed at the own brick (a line the wave requests anyway).
-template <int KIND>
-struct DmaX {
-  using TL = DenseTile<KIND>;
-  static constexpr int R = CubeTraits<KIND>::R;
-  static constexpr int T = 8 + 2 * R;
-  static constexpr int NI = (TL::ELEMS + 127) / 128;
-  static constexpr int QUADS = (NI + 3) / 4;
-};
-template <int KIND>
-struct DmaTable {
-  alignas(16) uint32_t e[DmaX<KIND>::QUADS * 256];
-};
-template <int KIND>
-constexpr DmaTable<KIND> make_dma_table() {
-  DmaTable<KIND> t{};
-  using X = DmaX<KIND>;
-  using TL = DenseTile<KIND>;
-  constexpr int R = X::R, T = X::T;
-  for (int q = 0; q < X::QUADS * 256; ++q) t.e[q] = 0xFFFFFFFFu;
-  for (int n = 0; n < X::NI * 64; ++n) {
-    const int q = n / 64, lane = n % 64;
-    const int e = q * 128 + lane * 2; // first of the two doubles this lane brings
-    if (e >= TL::ELEMS) continue;
-    const int row = e / 8, c = e % 8, kk = row / T + TL::KK0, jj = row % T;
-    int dk = kk < R ? -1 : (kk >= R + 8 ? 1 : 0), dj = jj < R ? -1 : (jj >= R + 8 ? 1 : 0);
-    if (KIND == kDiamond25) {
-      const int ek = kk < R ? R - kk : (kk >= R + 8 ? kk - R - 7 : 0), ej = jj < R ? R - jj : (jj >= R + 8 ? jj - R - 7 : 0);
-      if (ek + ej > 2) dk = 0, dj = 0; // never read: any address the wave touches anyway
-    }
-    const int sk = (kk - R + 8) % 8, sj = (jj - R + 8) % 8;
-    t.e[((q / 4) * 64 + lane) * 4 + q % 4] = ((uint32_t)adj_slot(dk, dj, 0) << 16) | ((uint32_t)(sk * 64 + sj * 8 + c) << 21);
-  }
-  return t;
-}
-__device__ const DmaTable<kCube27> g_dma27 = make_dma_table<kCube27>();
-__device__ const DmaTable<kCube125> g_dma125 = make_dma_table<kCube125>();
-__device__ const DmaTable<kDiamond25> g_dma_d25 = make_dma_table<kDiamond25>();
-template <int KIND>
-__device__ __forceinline__ const uint32_t *dma_table() {
-  if (KIND == kCube27) return g_dma27.e;
-  if (KIND == kCube125) return g_dma125.e;
-  return g_dma_d25.e;
-}
-#endif // BRK_VARIANTS
 
 __device__ const DenseExtra<kCube27> g_dense27 = make_dense_extra<kCube27>();
 __device__ const DenseExtra<kCube125> g_dense125 = make_dense_extra<kCube125>();
@@ -566,223 +516,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
 }
 
 #ifdef BRK_VARIANTS
-// k_cube_dma (round 4) -- the same tiles and the same accumulation as k_cube_dense, for REGISTERED adjacency tables, staged by LDS-DMA.
-// Correct (the whole GPU suite ran through it) and 10-19 % SLOWER than staging through registers: 27-point 0.465 vs 0.423 ms, 125-point
-// 0.672 vs 0.564, fused double 7-point pass 0.506 vs 0.437 (interleaved, placed storages, box and list form alike).  An LDS-DMA
-// instruction with per-lane source addresses costs the wave far more issue time than a global_load_dwordx4 with an SGPR base, and the
-// own brick can no longer be requested before the adjacency row is known.  Kept for A/B runs only (variant 15):
-//   * every wave works out the links of the whole group from scalars (the list entries, the compact face rows and the link bits of the
-//     registered table): no exchange through LDS, no barrier in front of the staging -- one barrier per group instead of two;
-//   * the whole own tile (own rows, k- / j-faces, kj-edge rows) arrives by ceil(ELEMS / 128) global_load_lds_dwordx4 instructions with
-//     per-lane source addresses (DmaTable): no staging registers, no ds_write for it; only what a wave WITHOUT an i-neighbour sibling
-//     needs on that side (i-face columns, i-side edge / corner cells) still travels through registers into the slot on that side;
-//   * groups whose runs had to be 2-coloured (two active neighbours that are not i-neighbours) keep the two phases of k_cube_dense:
-//     a phase-1 wave requests its tile only after phase 0 is done with the slots that lie inside it.
-typedef const __attribute__((address_space(1))) void *dma_src;
-typedef __attribute__((address_space(3))) void *dma_dst;
-
-template <int KIND, int NW, int OCC, int PIPE = 1>
-__global__ __launch_bounds__(64 * NW, OCC) void k_cube_dma(
-    const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out, size_t step,
-    const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf, const uint32_t *__restrict__ linkmask,
-    const uint32_t *__restrict__ faces, const uint32_t *__restrict__ cubemask, uint32_t cs1, uint32_t cs2) {
-  constexpr int R = CubeTraits<KIND>::R;
-  using TL = DenseTile<KIND>;
-  using X = DX<KIND>;
-  using DM = DmaX<KIND>;
-  constexpr int E = TL::ELEMS;
-  __shared__ double lds[(NW + 1) * E];
-  __shared__ double jslot[KIND == kCube125 && PIPE == 5 ? NW * 192 : 1];
-  const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + wg_in_xcd(cf, per_xcd);
-  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  const int hi = lane >> 3, lo = lane & 7;
-  double *tile = lds + (w + 1) * E;
-  double *left = tile - E;
-  const int roff = w == NW - 1 ? -NW * E : E;
-  double *right = tile + roff;
-
-  // descriptors (they depend on the lane only): requested before anything else
-  uint32_t dd[DM::NI], xd[X::EXTRA_ITERS];
-  {
-    const uint4 *dt = reinterpret_cast<const uint4 *>(dma_table<KIND>());
-#pragma unroll
-    for (int g = 0; g < DM::QUADS; ++g) {
-      const uint4 q = dt[g * 64 + lane];
-      if (4 * g < DM::NI) dd[4 * g] = q.x;
-      if (4 * g + 1 < DM::NI) dd[4 * g + 1] = q.y;
-      if (4 * g + 2 < DM::NI) dd[4 * g + 2] = q.z;
-      if (4 * g + 3 < DM::NI) dd[4 * g + 3] = q.w;
-    }
-    const uint4 *xt = reinterpret_cast<const uint4 *>(dense_table<KIND>());
-#pragma unroll
-    for (int g = 0; g < X::QUADS; ++g) {
-      const uint4 q = xt[g * 64 + lane];
-      if (4 * g < X::EXTRA_ITERS) xd[4 * g] = q.x;
-      if (4 * g + 1 < X::EXTRA_ITERS) xd[4 * g + 1] = q.y;
-      if (4 * g + 2 < X::EXTRA_ITERS) xd[4 * g + 2] = q.z;
-      if (4 * g + 3 < X::EXTRA_ITERS) xd[4 * g + 3] = q.w;
-    }
-  }
-  // ---- the group's bricks and the links between them: scalars, the same in every wave of the group
-  uint32_t gb[NW];
-#pragma unroll
-  for (int v = 0; v < NW; ++v) {
-    const uint32_t sl = wg * NW + v;
-    gb[v] = sl < n ? __builtin_amdgcn_readfirstlane(ids ? ids[sl] : first + sl) : BRK_LIST_SKIP;
-  }
-  uint32_t linkbits = 0; // bit v: entries v and v + 1 are i-neighbours that see the same world across their common face
-#pragma unroll
-  for (int v = 0; v + 1 < NW; ++v)
-    if (gb[v] != BRK_LIST_SKIP && gb[v + 1] != BRK_LIST_SKIP) {
-      const uint32_t bv = gb[v];
-      const uint32_t ip = faces[8 * (size_t)bv + 5];
-      const uint32_t rw = linkmask[4 * (size_t)(bv >> 6) + ((bv >> 4) & 2u) + 1];
-      if (ip == gb[v + 1] && ((rw >> (bv & 31u)) & 1u)) linkbits |= 1u << v;
-    }
-  linkbits = __builtin_amdgcn_readfirstlane(linkbits);
-  uint32_t bm = 0; // bit v: wave v starts a run that cannot share with the run in front of it
-#pragma unroll
-  for (int v = 1; v < NW; ++v)
-    if (gb[v] != BRK_LIST_SKIP && gb[v - 1] != BRK_LIST_SKIP && !((linkbits >> (v - 1)) & 1u)) bm |= 1u << v;
-  const int my_phase = __builtin_popcount(bm & ((2u << w) - 1u)) & 1;
-  const int nphase = bm ? 2 : 1;
-  uint32_t b = gb[0];
-#pragma unroll
-  for (int v = 1; v < NW; ++v)
-    if (w == (uint32_t)v) b = gb[v];
-  const bool active = b != BRK_LIST_SKIP;
-  const bool link_l = w > 0 && ((linkbits >> (w - 1)) & 1u), link_r = ((linkbits >> w) & 1u) != 0; // bit NW-1 is never set
-
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  typedef const __attribute__((address_space(1))) d2 *gc2;
-  constexpr bool W16 = R == 2;
-  double below = 0.0, above = 0.0, fim[R], fip[R], xv[X::EXTRA_ITERS];
-  d2 xv2[X::EXTRA_ITERS], im2 = {0.0, 0.0}, ip2 = {0.0, 0.0};
-  uint32_t arow = 0;
-  auto request_tile = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int q = 0; q < DM::NI; ++q) {
-      const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((dd[q] >> 16) & 31u) << 2), (int)arow);
-      const double *src = in + (size_t)nb * step + ((dd[q] >> 21) & 511u);
-      if (q * 128 + 126 < E || q * 128 + lane * 2 < E)
-        __builtin_amdgcn_global_load_lds((dma_src)src, (dma_dst)(tile + q * 128), 16, 0, 0);
-    }
-  };
-  if (active) {
-    const int l27 = lane < 27 ? lane : 13;
-    const bool predicted = cubemask && ((cubemask[b >> 5] >> (b & 31u)) & 1u);
-    if (predicted) arow = b + (uint32_t)(l27 / 9 - 1) * cs2 + (uint32_t)((l27 / 3) % 3 - 1) * cs1 + (uint32_t)(l27 % 3 - 1);
-    else arow = adj[(size_t)b * 27 + l27];
-    if (my_phase == 0) request_tile();
-    // the diamond's outermost levels stay in registers (lane = (j, i))
-    if (!TL::has_plane(0)) below = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(-1, 0, 0)) * step)[(8 - R) * 64 + lane];
-    if (!TL::has_plane(R + 8 + R - 1)) above = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(1, 0, 0)) * step)[(R - 1) * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < R; ++r) fim[r] = fip[r] = 0.0;
-    if (!link_l) {
-      const gcptr p_im = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 0, -1)) * step);
-      if (W16) im2 = *(gc2)(p_im + hi * 64 + lo * 8 + 6);
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (!W16) fim[r] = p_im[hi * 64 + lo * 8 + (8 - R + r)];
-    }
-    if (!link_r) {
-      const gcptr p_ip = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 0, 1)) * step);
-      if (W16) ip2 = *(gc2)(p_ip + hi * 64 + lo * 8);
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if (!W16) fip[r] = p_ip[hi * 64 + lo * 8 + r];
-    }
-    auto gather = [&](int t) {
-      const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((xd[t] >> 16) & 31u) << 2), (int)arow);
-      if (X::PAIR) xv2[t] = xd[t] != 0xFFFFFFFFu ? *(const d2 *)(in + (size_t)nb * step + ((xd[t] >> 21) & 511u)) : d2{0.0, 0.0};
-      else xv[t] = xd[t] != 0xFFFFFFFFu ? in[(size_t)nb * step + ((xd[t] >> 21) & 511u)] : 0.0;
-    };
-    if (!link_l) {
-#pragma unroll
-      for (int t = X::IT0; t < X::IT0 + X::ITS; ++t) gather(t);
-    }
-    if (!link_r) {
-#pragma unroll
-      for (int t = X::IT0 + X::ITS; t < X::EXTRA_ITERS; ++t) gather(t);
-    }
-  }
-
-  gptr dst = (gptr)(out + (size_t)(active ? b : 0) * step);
-  asm volatile("" : "+s"(dst));
-  for (int ph = 0; ph < nphase; ++ph) {
-    const bool mine = active && my_phase == ph;
-    if (mine) {
-      if (ph == 1) request_tile(); // phase 0 has finished with the slots inside this tile
-      if (!link_l) {
-        if (W16) *(d2 *)&left[TL::at(hi + R, lo + R, 8 - R)] = im2;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (!W16) left[TL::at(hi + R, lo + R, 8 - R + r)] = fim[r];
-#pragma unroll
-        for (int t = X::IT0; t < X::IT0 + X::ITS; ++t)
-          if (xd[t] != 0xFFFFFFFFu) {
-            if (X::PAIR) *(d2 *)&left[xd[t] & 0xFFFFu] = xv2[t];
-            else left[xd[t] & 0xFFFFu] = xv[t];
-          }
-      }
-      if (!link_r) {
-        if (W16) *(d2 *)&right[TL::at(hi + R, lo + R, 0)] = ip2;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (!W16) right[TL::at(hi + R, lo + R, r)] = fip[r];
-#pragma unroll
-        for (int t = X::IT0 + X::ITS; t < X::EXTRA_ITERS; ++t)
-          if (xd[t] != 0xFFFFFFFFu) {
-            if (X::PAIR) *(d2 *)&right[xd[t] & 0xFFFFu] = xv2[t];
-            else right[xd[t] & 0xFFFFu] = xv[t];
-          }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the tile has landed (LDS-DMA is counted in vmcnt)
-    __syncthreads();                                  // the tiles of this phase are complete
-    if (mine) {
-      int col[2 * R + 1];
-#pragma unroll
-      for (int di = -R; di <= R; ++di) {
-        const int c = lo + di;
-        col[di + R] = c < 0 ? -E + c + 8 : (c > 7 ? roff + c - 8 : c);
-      }
-      if (KIND == kDiamond25) {
-        const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
-        diamond25_accumulate<TL::T * 8, 8, PIPE == 1>(tile + TL::at(0, hi + R, 0), co, cf, dst, lane, below, above);
-      } else if (KIND == kCube125) {
-        const int co[5] = {col[0], col[1], col[2], col[3], col[4]};
-        cube125_accumulate_jout<TL::T * 8, 8>(tile, co, cf, jslot + (KIND == kCube125 && PIPE == 5 ? w * 192 : 0), (double *)dst, lane);
-      } else {
-        double acc[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = 0.0;
-        const int rowbase = (hi + R) * 8;
-#pragma unroll
-        for (int kk = 0; kk < TL::T; ++kk) {
-#pragma unroll
-          for (int dj = -R; dj <= R; ++dj)
-#pragma unroll
-            for (int di = -R; di <= R; ++di) {
-              const double v = tile[kk * TL::T * 8 + dj * 8 + rowbase + col[di + R]];
-#pragma unroll
-              for (int dk = -R; dk <= R; ++dk) {
-                const int k = kk - R - dk; // output plane fed through tap dk
-                if (k >= 0 && k < 8) acc[k] += cf.c[adj_slot(dk, dj, di)] * v;
-              }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
-      }
-    }
-    if (ph + 1 < nphase) __syncthreads(); // phase 1 overwrites slots phase 0 was reading
-  }
-}
-#endif // BRK_VARIANTS
+#define BRK_VARIANTS_PART 1
+#include "brk_cubedense_variants.hip"
+#undef BRK_VARIANTS_PART
+#endif
 
 } // namespace
 
@@ -799,34 +536,16 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
 #endif
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8;
   const bool x2 = stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2;
-#define BRK_CD(KIND, NW, OCC, PIPE, WGS, LDS) \
-  hipLaunchKernelGGL((k_cube_dense<KIND, NW, OCC, PIPE>), dim3(WGS), dim3(64 * NW), LDS, st, adj, in, out, step, ids, first, n, cf, g_diag, linkmask, cubereg.mask, cubereg.s1, cubereg.s2)
+#define BRK_CD(KIND, NW, OCC, PIPE, WGS, LDS)                                                                                          \
+  do {                                                                                                                                 \
+    brk_note_kernel("k_cube_dense<" #KIND "," #NW "," #OCC "," #PIPE ">");                                                             \
+    hipLaunchKernelGGL((k_cube_dense<KIND, NW, OCC, PIPE>), dim3(WGS), dim3(64 * NW), LDS, st, adj, in, out, step, ids, first, n, cf, \
+                       g_diag, linkmask, cubereg.mask, cubereg.s1, cubereg.s2);                                                        \
+  } while (0)
 #ifdef BRK_VARIANTS
-  if (variant == 15 && linkmask && cubereg.faces) { // registered tables: the LDS-DMA staged kernels (slower; see k_cube_dma)
-#define BRK_CDMA(KIND, NW, OCC, PIPE) \
-  hipLaunchKernelGGL((k_cube_dma<KIND, NW, OCC, PIPE>), dim3(wgs4), dim3(64 * NW), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, linkmask, cubereg.faces, cubereg.mask, cubereg.s1, cubereg.s2)
-    if (x2) BRK_CDMA(kDiamond25, 4, 4, 1);
-    else if (stencil_id == BRK_27PT_COEFF) BRK_CDMA(kCube27, 4, 5, 1);
-    else BRK_CDMA(kCube125, 4, 3, 5);
-#undef BRK_CDMA
-    HIP_TRY(hipGetLastError());
-    return BRK_OK;
-  }
-  const uint32_t wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
-  bool done = true;
-  if (x2 && variant == 2) BRK_CD(kDiamond25, 4, 4, 1, wgs4, g_pad_lds);                       // plane loop with read-ahead, 8-byte staging (the default until round 4)
-  else if (stencil_id == BRK_27PT_COEFF && variant == 5) BRK_CD(kCube27, 8, 4, 1, wgs8, g_pad_lds);
-  else if (stencil_id == BRK_MPI125 && variant == 6) BRK_CD(kCube125, 4, 2, 1, wgs4, g_pad_lds);
-  else if (stencil_id == BRK_MPI125 && variant == 7) BRK_CD(kCube125, 8, 2, 1, wgs8, g_pad_lds);
-  else if (stencil_id == BRK_MPI125 && variant == 11) BRK_CD(kCube125, 4, 3, 4, wgs4, g_pad_lds); // row-pipelined plane loop, 5 rows in flight (spills)
-  else if (stencil_id == BRK_MPI125 && variant == 10) BRK_CD(kCube125, 4, 3, 3, wgs4, g_pad_lds); // input-side accumulation, row-pipelined plane loop
-  else if (stencil_id == BRK_MPI125 && variant == 9) BRK_CD(kCube125, 4, 3, 0, wgs4, g_pad_lds);
-  else if (stencil_id == BRK_MPI125 && variant == 5) BRK_CD(kCube125, 4, 3, 2, wgs4, g_pad_lds);  // fully unrolled plane loop (the round-1 default)
-  else done = false;
-  if (done) {
-    HIP_TRY(hipGetLastError());
-    return BRK_OK;
-  }
+#define BRK_VARIANTS_PART 2
+#include "brk_cubedense_variants.hip"
+#undef BRK_VARIANTS_PART
 #endif
   (void)variant;
   if (x2) BRK_CD(kDiamond25, 4, 4, 0, wgs4, g_pad_lds); // plane loop without read-ahead, 16-byte staging (see LD16)

@@ -1,4 +1,4 @@
-// brk_cubewg.hip -- cube stencils (27- and 125-point) with workgroup-shared i-halos.
+// brk_cubewg_variants.hip -- cube stencils (27- and 125-point) with workgroup-shared i-halos.
 //
 // One wave per brick, NW consecutive list entries per workgroup, full (8+2R)^3 LDS tile per wave (CubeTile of
 // brick-device.h: k/j faces by structured coalesced loads, edge/corner cells through the descriptor table).  Every

@@ -56,7 +56,7 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *faces, bool kpaired);
 
 // 27-/125-point kernels: dense conflict-free tiles with sibling/fallback slots (brk_cubedense.hip), and the earlier padded
-// tiles with shared i-halos (brk_cubewg.hip)
+// tiles with shared i-halos (brk_cubewg_variants.hip)
 // `cubereg`: the box entry point over a registered table -- one bit per brick "all 26 neighbours are the ids the lexicographic
 // numbering with strides (s1, s2) predicts" (k_regular_mask, cube form): such a brick's adjacency row is computed, not loaded
 struct CubeRegular {

@@ -5,6 +5,11 @@
 
 // records the message for brk_last_error() and returns `code`
 int brk_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// records, per calling thread, the name of the stencil kernel a launcher is about to enqueue (string literal): brk_last_kernel()
+#ifdef __cplusplus
+extern "C"
+#endif
+void brk_note_kernel(const char *name);
 
 #ifdef __cplusplus
 #include <array>

@@ -661,6 +661,45 @@ extern "C" int brk_adjacency_release(const uint32_t *adj_dev) {
   return brk_fail(BRK_EINVAL, "brk_adjacency_release: table %p is not registered", (const void *)adj_dev);
 }
 
+// Orderly end of the library's use of the GPU, for a process that is about to leave main(): every launch and copy the library has
+// enqueued on the current device has finished when this returns, and what the library itself holds on a device -- the box id lists
+// with their events, retired lists, the derived tables of adjacency tables that are still registered -- is released by the
+// CALLING thread, not by static destructors racing the HIP runtime's own exit handlers.  Caller memory is not
+// touched; the library stays usable (caches are rebuilt on demand, registrations are forgotten).
+extern "C" int brk_finalize(void) {
+  HIP_TRY(hipDeviceSynchronize());
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  {
+    std::lock_guard<std::mutex> lock(g_box_mutex);
+    auto on = [&](int d) { // lists live on the device they were built on
+      if (d != device) (void)hipSetDevice(d);
+    };
+    for (BoxList &e : g_box)
+      if (e.dev) {
+        on(e.device);
+        (void)hipEventSynchronize(e.last_use);
+        (void)hipFree(e.dev);
+        (void)hipEventDestroy(e.last_use);
+        if (e.device != device) (void)hipSetDevice(device);
+        e = BoxList{};
+      }
+    for (RetiredList &r : g_box_retired) { // the event knows its device; hipFree finds the allocation's
+      (void)hipEventSynchronize(r.last_use);
+      (void)hipFree(r.dev);
+      (void)hipEventDestroy(r.last_use);
+    }
+    g_box_retired.clear();
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_adj_mutex);
+    for (AdjEntry &e : g_adj) free_entry(e);
+    g_adj.clear();
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  return BRK_OK;
+}
+
 extern "C" int brk_stencil_apply_range(int id, const uint32_t *adj, const double *in, double *out, size_t step,
                                        uint32_t begin, uint32_t end, const double *coeff_host, brk_stream s) {
   if (end < begin) return brk_fail(BRK_EINVAL, "brick range [%u,%u) is reversed", begin, end);

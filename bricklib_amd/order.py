@@ -80,16 +80,24 @@ def tiled(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True, kpair=False):
     return assemble(slabs(ids3, rows_per_block, nxcd, pad_rows, kpair), nxcd=nxcd)
 
 
-def tiled_scattered(ids, gi, gj, gk, rows_per_block=8, nxcd=NXCD):
+def tiled_scattered(ids, gi, gj, gk, rows_per_block=8, nxcd=NXCD, kpair=False):
     """The tiled order for bricks given by coordinates instead of a box: `ids` with brick coordinates (gi, gj, gk) in any common
     frame (several subdomains of one rank in the global frame, holes and duplicates allowed).  Same traversal as slabs(): XCD x gets
     its slab of j-rows, swept in blocks of <= rows_per_block rows (None: chosen from the row length) over all k with i fastest,
-    left-over rows are cut along k; runs of i-neighbours stay together and a LIST_SKIP entry follows every run whose length is not a multiple of 8."""
+    left-over rows are cut along k; runs of i-neighbours stay together and a LIST_SKIP entry follows every run whose length is not a multiple of 8.
+    kpair: the k-paired order of tiled(..., kpair=True) over the bounding box of the coordinates, LIST_SKIP where the box has no
+    brick (no duplicates then): groups of 8 entries = 4 i-neighbours + their +k neighbours; a group with a hole is computed one
+    brick at a time by the march kernel, so this pays for brick sets that are mostly a box (a subdomain minus aliased ghost faces)."""
     ids = np.asarray(ids, dtype=np.uint32)
     if ids.size == 0:
         return np.zeros(0, dtype=np.uint32)
     gi, gj, gk = (np.asarray(c, dtype=np.int64) - int(np.min(c)) for c in (gi, gj, gk))
     J, K = int(gj.max()) + 1, int(gk.max()) + 1
+    if kpair:
+        box = np.full((K, J, int(gi.max()) + 1), LIST_SKIP, dtype=np.uint32)
+        assert np.unique(np.stack([gk, gj, gi]), axis=1).shape[1] == ids.size, "k-paired order: one brick per coordinate"
+        box[gk, gj, gi] = ids
+        return tiled(box, rows_per_block or 8, nxcd, kpair=True)
     if rows_per_block is None:       # a block of rows of one k-plane stays within ~2 MiB (512 bricks), the measured optimum at 512^3
         rows_per_block = max(1, min(8, 512 // (int(gi.max()) + 1)))
     base = J // nxcd

@@ -56,6 +56,16 @@ def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coef
                                              _stream(stream)))
 
 
+def last_kernel():
+    """Name (template arguments included) of the kernel the last stencil launch of the calling thread enqueued (brk_last_kernel)."""
+    return lib.brk_last_kernel().decode()
+
+
+def finalize():
+    """brk_finalize: wait for the library's work on the current device and release its device-side caches (before process exit)."""
+    check(lib.brk_finalize())
+
+
 class Zigzag:
     """Direction of successive sweeps over the same bricks: `z.turn()` returns False, True, False, ... -- pass it as `reverse=`."""
 

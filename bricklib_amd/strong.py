@@ -95,17 +95,20 @@ def strong_tables(d, l, r, rank, size, subdim, alias_local=True):
     return copies, msgs, peers, alias
 
 
-def strong_lists(d, nsub, alias, rows_per_block=8):
+def strong_lists(d, nsub, alias, rows_per_block=8, kpair=False):
     """(adjacency, list_all, list_domain) of a rank's nsub subdomains in one storage: block-diagonal adjacency (brick ids of
     subdomain m shifted by m*nbricks) with every aliased ghost brick replaced by its source, the sweep list over subdomains +
     ghost rings without the aliased ghost bricks (one tiled list per pattern of local neighbours), and the list of the subdomains
     themselves.  The lists stay subdomain after subdomain: measured on config 5 (1024^3 in 128^3 subdomains, one GPU, 13-point
     star) 13.1 ms per step, against 13.4 (8-row blocks) / 13.8 (4-row blocks) for ONE tiled sweep of the rank's bricks in the global
     frame -- rows of 128 bricks share more halos through LDS, but a subdomain is also a 16 x 16 x 16 cache tile whose faces come
-    back from L2, and that is worth more."""
+    back from L2, and that is worth more.
+    kpair: both lists in the k-paired order (order.tiled(..., kpair=True)) for sweeps of the 13- / 25-point stars through
+    brk_stencil_apply_list_kpaired (two bricks per wave, k_star_km); a subdomain with aliased ghost faces is the k-paired order of its
+    bounding box with LIST_SKIP in the holes."""
     nb = d.nbricks
     adj = np.concatenate([d.adj.astype(np.uint64) + m * nb for m in range(nsub)]).astype(np.uint32)
-    lists = decomp_lists(d, rows_per_block)
+    lists = decomp_lists(d, rows_per_block, kpair=kpair)
     shift = lambda ids, m: np.where(ids == LIST_SKIP, ids, ids + np.uint32(m * nb)).astype(np.uint32)
     own = (alias == np.arange(alias.size, dtype=np.uint32)).reshape(nsub, nb)
     g3 = np.asarray(d.grid).astype(np.uint32)                    # [k][j][i] of the ghosted grid -> local brick id
@@ -116,13 +119,13 @@ def strong_lists(d, nsub, alias, rows_per_block=8):
         key = own[m].tobytes()
         if key not in cache:
             keep = own[m][loc]
-            cache[key] = lists["all"] if keep.all() else tiled_scattered(loc[keep], ii[keep], jj[keep], kk[keep], rows_per_block)
+            cache[key] = lists["all"] if keep.all() else tiled_scattered(loc[keep], ii[keep], jj[keep], kk[keep], rows_per_block, kpair=kpair)
         parts.append(shift(cache[key], m))
     return alias[adj], np.concatenate(parts), np.concatenate([shift(lists["domain"], m) for m in range(nsub)])
 
 
 class StrongRank:
-    def __init__(self, dom, sdom, rank, size, device, rows_per_block=8, alias_local=True):
+    def __init__(self, dom, sdom, rank, size, device, rows_per_block=8, alias_local=True, kpair=True):
         assert dom % sdom == 0 and (dom // sdom) & (dom // sdom - 1) == 0, "blocks per axis must be a power of two"
         self.dom, self.sdom, self.rank, self.size, self.device = dom, sdom, rank, size, torch.device(device)
         self.subdim = dom // sdom
@@ -132,8 +135,12 @@ class StrongRank:
         d = self.d = BrickDecomp((sdom, sdom, sdom), 8)        # ONE decomposition shared by all subdomains (strong/main.cpp:91-94)
         nb = self.nb = d.nbricks
         self.alias_local = bool(alias_local)
+        self.kpair = bool(kpair)
         copies, msgs, self.peers, self.alias = strong_tables(d, self.l, self.r, rank, size, self.subdim, self.alias_local)
         adj, list_all, list_domain = strong_lists(d, self.nsub, self.alias, rows_per_block)
+        self.rows_per_block = rows_per_block
+        self._paired = None      # (list_all, list_domain, complete fraction) in the k-paired order, built on the first sweep of a star stencil
+        self.swept_kpaired = False
         self.info = BrickInfo(adj, self.device)
         self.storages = [BrickStorage.allocate(self.nsub * nb, 512, self.device) for _ in range(3)]
         self.bricks = [Brick(self.info, st, 0) for st in self.storages]
@@ -180,12 +187,31 @@ class StrongRank:
         b = self.bricks
         zz = Zigzag()
         rev = lambda: zigzag and zz.turn()
-        apply_stencil(stencil, b[0], b[1], ids=self.list_all, coeff=coeff, stream=stream, reverse=rev())
+        # the 13- and 25-point stars sweep the same bricks in the k-paired order (two bricks per wave, k_star_km: round 5; the
+        # results do not depend on the order); every other stencil keeps the plain tiled lists
+        # -- when at least 90 % of the swept bricks lie in complete groups (4 i-neighbours + their 4 +k neighbours: a subdomain whose
+        # ghost faces are all aliased is a 16^3 box, all complete; with 8 ranks x 64 subdomains of 128^3 the kept ghost faces make the
+        # extents 17 / 18 and only 77 % complete -- the march kernel computes incomplete groups one brick at a time, which costs more
+        # than the pairing gains)
+        kp = self.kpair and stencil in ("mpi13pt", "mpi25pt") and self.paired_lists()[2] >= 0.9
+        la, ld = self.paired_lists()[:2] if kp else (self.list_all, self.list_domain)
+        self.swept_kpaired = bool(kp)
+        apply_stencil(stencil, b[0], b[1], ids=la, coeff=coeff, stream=stream, reverse=rev(), kpaired=kp)
         for _ in range(S // 2 - 1):
-            apply_stencil(stencil, b[1], b[2], ids=self.list_all, coeff=coeff, stream=stream, reverse=rev())
-            apply_stencil(stencil, b[2], b[1], ids=self.list_all, coeff=coeff, stream=stream, reverse=rev())
-        apply_stencil(stencil, b[1], b[0], ids=self.list_domain, coeff=coeff, stream=stream, reverse=rev())
+            apply_stencil(stencil, b[1], b[2], ids=la, coeff=coeff, stream=stream, reverse=rev(), kpaired=kp)
+            apply_stencil(stencil, b[2], b[1], ids=la, coeff=coeff, stream=stream, reverse=rev(), kpaired=kp)
+        apply_stencil(stencil, b[1], b[0], ids=ld, coeff=coeff, stream=stream, reverse=rev(), kpaired=kp)
         return S
+
+    def paired_lists(self):
+        """(list_all, list_domain, fraction of list_all's bricks in complete groups of 8) in the k-paired order, lists on the device;
+        same bricks as the plain lists (checked)."""
+        if self._paired is None:
+            _, la, ld = strong_lists(self.d, self.nsub, self.alias, self.rows_per_block, kpair=True)
+            assert int((la != LIST_SKIP).sum()) == self.swept_bricks
+            complete = int((la.reshape(-1, 8) != LIST_SKIP).all(axis=1).sum()) * 8
+            self._paired = (grid_to_device(la, self.device), grid_to_device(ld, self.device), complete / max(self.swept_bricks, 1))
+        return self._paired
 
 
 def rccl_transport(comm):

@@ -4,10 +4,17 @@
 // the signal -- but a crash that happens once in a few hundred runs leaves its address behind.  Background:
 // examples/strong_hip has died during process exit, after its validated result and timing line, about once in a few hundred runs;
 // every host path of this repository is clean under AddressSanitizer (tests/test_sanitized_host_paths.py).
+// Round 5 additions: snapshot() may be called again (after GPU initialisation, just before main returns) so that libraries the
+// runtime dlopens lazily are in the picture; the handler also prints the nearest mapping BELOW an unmapped program counter and the
+// register context (RSP, RBP, the return address at [RSP]); census(label) prints every thread of the process with its id and name --
+// BRK_CENSUS=1 in the environment makes the drivers do that at four points of main() (who owns tid = pid + 1).
 #pragma once
+#include <dirent.h>
 #include <execinfo.h>
 #include <fcntl.h>
 #include <signal.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/syscall.h>
 #include <ucontext.h>
@@ -17,6 +24,8 @@ namespace brk_crash {
 constexpr int kMapsMax = 1 << 17;
 inline char g_maps[kMapsMax]; // /proc/self/maps as it was when main() started
 inline int g_maps_len = 0;
+inline char g_maps_late[kMapsMax]; // ... and at the latest snapshot() (after GPU initialisation / before main returns)
+inline int g_maps_late_len = 0;
 
 inline void say(const char *s) { (void)!write(2, s, strlen(s)); }
 inline void say_hex(unsigned long v) {
@@ -82,6 +91,34 @@ inline bool say_mapping(const char *maps, int len, unsigned long addr) {
   }
   return false;
 }
+// the line of a maps text with the highest end address <= addr (what lay just below an unmapped address), printed to stderr
+inline bool say_mapping_below(const char *maps, int len, unsigned long addr) {
+  int p = 0, best_p = -1, best_e = -1;
+  unsigned long best_hi = 0;
+  while (p < len) {
+    int e = p;
+    while (e < len && maps[e] != '\n') ++e;
+    unsigned long lo = 0, hi = 0;
+    int q = p;
+    auto hex = [&](unsigned long &v) {
+      for (; q < e; ++q) {
+        const char c = maps[q];
+        const int d = c >= '0' && c <= '9' ? c - '0' : (c >= 'a' && c <= 'f' ? c - 'a' + 10 : -1);
+        if (d < 0) break;
+        v = v * 16 + (unsigned long)d;
+      }
+    };
+    hex(lo);
+    ++q;
+    hex(hi);
+    if (hi <= addr && hi > best_hi) best_hi = hi, best_p = p, best_e = e;
+    p = e + 1;
+  }
+  if (best_p < 0) return false;
+  (void)!write(2, maps + best_p, (size_t)(best_e - best_p));
+  say("\n");
+  return true;
+}
 inline void handler(int sig, siginfo_t *info, void *uctx) {
   const long tid = (long)syscall(SYS_gettid), pid = (long)getpid();
   const unsigned long pc = (unsigned long)((ucontext_t *)uctx)->uc_mcontext.gregs[REG_RIP];
@@ -109,10 +146,37 @@ inline void handler(int sig, siginfo_t *info, void *uctx) {
   say_hex(pc);
   say("\n[crash_trace] mapped at that program counter when main() started: ");
   if (!say_mapping(g_maps, g_maps_len, pc)) say("nothing\n");
+  say("[crash_trace] mapped there at the latest snapshot (GPU initialised): ");
+  if (!say_mapping(g_maps_late, g_maps_late_len, pc)) {
+    say("nothing; nearest mapping below it then: ");
+    if (!say_mapping_below(g_maps_late, g_maps_late_len, pc)) say("none\n");
+  }
   static char now[kMapsMax];
   const int now_len = slurp("/proc/self/maps", now, kMapsMax);
   say("[crash_trace] mapped there now: ");
-  if (!say_mapping(now, now_len, pc)) say("nothing (code that has been unmapped, or a wild jump)\n");
+  if (!say_mapping(now, now_len, pc)) {
+    say("nothing (code that has been unmapped, or a wild jump); nearest mapping below it now: ");
+    if (!say_mapping_below(now, now_len, pc)) say("none\n");
+  }
+  {
+    const greg_t *gr = ((ucontext_t *)uctx)->uc_mcontext.gregs;
+    const unsigned long rsp = (unsigned long)gr[REG_RSP], rbp = (unsigned long)gr[REG_RBP];
+    say("[crash_trace] rsp ");
+    say_hex(rsp);
+    say(", rbp ");
+    say_hex(rbp);
+    // the word at [rsp] is the return address when the fault is the first instruction after a call through a bad pointer;
+    // read it through /proc/self/mem so that a bad stack pointer cannot fault the handler
+    const int fd = open("/proc/self/mem", O_RDONLY);
+    unsigned long ret = 0;
+    if (fd >= 0 && pread(fd, &ret, sizeof ret, (off_t)rsp) == (long)sizeof ret) {
+      say(", [rsp] ");
+      say_hex(ret);
+      say(" which lies in: ");
+      if (!say_mapping(now, now_len, ret)) say("nothing mapped\n");
+    } else say("\n");
+    if (fd >= 0) close(fd);
+  }
   say("[crash_trace] call stack:\n");
   void *frames[48];
   const int n = backtrace(frames, 48);
@@ -121,10 +185,32 @@ inline void handler(int sig, siginfo_t *info, void *uctx) {
   signal(sig, SIG_DFL);
   raise(sig);
 }
+// take the picture of /proc/self/maps again: after the first HIP call, before main returns
+inline void snapshot() { g_maps_late_len = slurp("/proc/self/maps", g_maps_late, kMapsMax); }
+// every thread of this process: id, name (comm); printed only when BRK_CENSUS is set.  Not for use inside the handler.
+inline void census(const char *label) {
+  const char *want = getenv("BRK_CENSUS");
+  if (!want || !*want || *want == '0') return;
+  fprintf(stderr, "[census] %s: pid %ld;", label, (long)getpid());
+  if (DIR *d = opendir("/proc/self/task")) {
+    while (struct dirent *e = readdir(d)) {
+      if (e->d_name[0] == '.') continue;
+      char path[96], name[64] = "?";
+      snprintf(path, sizeof path, "/proc/self/task/%s/comm", e->d_name);
+      const int n = slurp(path, name, sizeof name);
+      if (n > 0 && name[n - 1] == '\n') name[n - 1] = 0;
+      fprintf(stderr, " %s=%s", e->d_name, name);
+    }
+    closedir(d);
+  }
+  fprintf(stderr, "\n");
+}
 inline void install() {
   void *warm[2];
   (void)backtrace(warm, 2); // loads libgcc's unwinder now, not inside the handler
   g_maps_len = slurp("/proc/self/maps", g_maps, kMapsMax);
+  memcpy(g_maps_late, g_maps, (size_t)g_maps_len + 1);
+  g_maps_late_len = g_maps_len;
   struct sigaction sa;
   memset(&sa, 0, sizeof sa);
   sa.sa_sigaction = handler;

@@ -77,8 +77,7 @@ __global__ void star37_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Br
   brick("star37.py", VSVEC, (BDIM), (VFOLD), b);
 }
 
-int main() {
-  brk_crash::install(); // a crash prints its thread and call stack before the process dies by the signal (crash_trace.h)
+static int run() {
   bElem *coeff = (bElem *)malloc(COEFF_SIZE * sizeof(bElem));
   {
     bElem *r = randomArray({COEFF_SIZE});
@@ -217,4 +216,17 @@ int main() {
     check("brick() star37 kernel (radius-3 star script read as data)");
   }
   return 0;
+}
+
+// brkFinalize (brick-gpu.h): OpenMP workers joined, the library's device-side caches released and the device idle before exit()
+// runs its handlers; what run() allocated on the device and did not free goes with the process, as in the
+// reference's driver
+int main() {
+  brk_crash::install(); // a crash prints its thread and call stack before the process dies by the signal (crash_trace.h)
+  brk_crash::census("first line of main");
+  const int rc = run();
+  brk_crash::snapshot();
+  brkFinalize();
+  brk_crash::census("just before return");
+  return rc;
 }

@@ -61,6 +61,7 @@ struct Rank {
 int main(int argc, char **argv) {
   setvbuf(stdout, nullptr, _IOLBF, 0); // the report survives whatever happens later, also into a pipe
   brk_crash::install(); // a crash prints its thread and call stack before the process dies by the signal (crash_trace.h)
+  brk_crash::census("first line of main"); // BRK_CENSUS=1: threads born in library constructors are the ones listed here
   const long d = argc > 1 ? atol(argv[1]) : 64, s = argc > 2 ? atol(argv[2]) : 16;
   const int size = argc > 3 ? atoi(argv[3]) : 3;
   const bool alias_local = !(argc > 4 && std::string(argv[4]) == "copy");
@@ -184,6 +185,8 @@ int main(int argc, char **argv) {
            brk_xplan_bytes_local(R.plan) / 1e6, R.n_all, (uint32_t)(R.nsub * (bd.sep_pos[2] - 1)), alias_local ? "local ghosts aliased" : "local ghosts copied");
   }
 
+  brk_crash::census("after the first HIP calls (storages, tables, views of every rank)");
+  brk_crash::snapshot(); // libraries the runtime loads lazily are mapped now
   std::vector<brk_exchange_view *> views;
   for (auto &R : ranks) views.push_back(R.view);
   const int S = brk_stencil_iters(BRK_MPI13);
@@ -223,6 +226,7 @@ int main(int argc, char **argv) {
               B0 * at(ga, x, y, z);
     ga.swap(gb);
   }
+  brk_crash::census("after the first omp parallel regions (CPU validation sweeps)");
   double worst = 0.0;
   for (auto &R : ranks) {
     std::vector<double> host(R.nsub * nb * 512);
@@ -260,5 +264,10 @@ int main(int argc, char **argv) {
     gpuCheck(hipFree(R.list_domain));
   }
   free(one.adj);
+  // orderly end (brick-gpu.h): OpenMP workers joined, the library's device-side caches released, the device idle -- on this thread,
+  // before exit() runs the handlers of the HIP runtime beside its own threads
+  brkFinalize();
+  brk_crash::census("just before return");
+  brk_crash::snapshot();
   return ok ? 0 : 1;
 }

@@ -28,8 +28,7 @@ int MPI_ITER = 20;
     }                                                             \
   } while (0)
 
-int main(int argc, char **argv) {
-  brk_crash::install(); // a crash prints its thread and call stack before the process dies by the signal (crash_trace.h)
+static int run(int argc, char **argv) {
   const unsigned N = argc > 1 ? (unsigned)atoi(argv[1]) : 64;
   BrickDecomp<3, 8, 8, 8> bDecomp({N, N, N}, 8);
   bDecomp.initialize(skin3d_good);
@@ -124,4 +123,16 @@ int main(int argc, char **argv) {
   free(bInfo.adj);
   std::cout << (ok ? "weak_hip: all exchanges match" : "weak_hip: FAILED") << std::endl;
   return ok ? 0 : 1;
+}
+
+// every device object of run() -- storages, the registered adjacency, views -- is gone when it returns; brkFinalize (brick-gpu.h)
+// then ends the library's and the process's use of the GPU on this thread, before exit() runs
+int main(int argc, char **argv) {
+  brk_crash::install(); // a crash prints its thread and call stack before the process dies by the signal (crash_trace.h)
+  brk_crash::census("first line of main");
+  const int rc = run(argc, argv);
+  brk_crash::snapshot();
+  brkFinalize();
+  brk_crash::census("just before return");
+  return rc;
 }

@@ -198,6 +198,7 @@ int main(int argc, char **argv) {
     fprintf(stderr, "weak_hip_mpi (world rank %d): %s\n", wrank, e.what());
     MPI_Abort(MPI_COMM_WORLD, 2);
   }
+  brkFinalize(); // OpenMP workers joined, the library's device-side caches released, the device idle (brick-gpu.h)
   MPI_Finalize();
   return rc;
 }

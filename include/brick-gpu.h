@@ -9,6 +9,9 @@
 
 #include "brick.h"
 #include "brk.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define gpuCheck(x) _gpuCheck(x, #x, __FILE__, __LINE__)
 
@@ -111,6 +114,23 @@ inline BrickStorage movBrickStorage(BrickStorage &bStorage, gpuMemcpyKind kind) 
     ret.dat = std::shared_ptr<bElem>(datptr, [](bElem *p) { free(p); });
   }
   return ret;
+}
+
+// OPTIONAL (not in the reference): the LAST device-related line of a driver's main(), after its own gpuFree calls.  Ends the process's
+// use of the GPU in a fixed order on the calling thread instead of leaving it to exit handlers that run beside the runtime's own
+// threads (an exit-time SIGSEGV of examples/strong_hip in a thread of the runtime, seen only in drivers that
+// are linked against OpenMP and leave main within its workers' spin-wait):
+//   1. the OpenMP runtime is shut down (workers joined) -- they otherwise spin for KMP_BLOCKTIME = 200 ms after the last parallel
+//      region, on every core, while the process exits;
+//   2. brk_finalize(): everything the library enqueued has finished, its device-side caches are released here;
+//   3. the device is idle when exit() starts running atexit handlers (the fat-binary unregistration of the executable and of
+//      libbrk.so among them).
+inline void brkFinalize() {
+#ifdef _OPENMP
+  (void)omp_pause_resource_all(omp_pause_hard);
+#endif
+  if (brk_finalize() != BRK_OK) printf("brk_finalize: %s\n", brk_last_error());
+  (void)gpuDeviceSynchronize();
 }
 
 #endif // BRICK_GPU_FUNCS_H

@@ -62,8 +62,19 @@ const char *brk_last_error(void);
 /* version of this ABI: 1000 + additions (1001: brk_stencil_apply_taps, 1002: the fused double-sweep stencil ids,
  * 1003: the ghost-zone exchange: brk_xplan_*, brk_exchange_*, brk_comm_*; 1004: brk_adjacency_register / _release;
  * 1005: brk_stencil_apply_{range,list,box}_ex with BRK_SWEEP_* flags; 1006: brk_comm_library, the development knob
- * brk_set_variant is no longer part of the ABI; 1007: brk_storage_alloc / brk_storage_free / brk_placement_probe) */
+ * brk_set_variant is no longer part of the ABI; 1007: brk_storage_alloc / brk_storage_free / brk_placement_probe;
+ * 1008: brk_finalize, brk_last_kernel) */
 int brk_abi_version(void);
+/* Orderly end of the library's use of the GPU before a process leaves main(): waits for everything enqueued on the current device
+ * and releases, on the CALLING thread, what the library itself holds there (box id lists and their events, derived tables of
+ * adjacency tables still registered).  Caller memory is not touched and the library stays usable.  The reference's drivers end
+ * with hipFree + return (stencils/3axis.hip.cpp:193-200, weak/main.cu:330-340); a driver over this library adds this one call
+ * in front of its return so that no device object is left to static destructors, which run concurrently with the HIP runtime's
+ * own exit handlers. */
+int brk_finalize(void);
+/* Name of the kernel (template arguments included, e.g. "k_star_km<kStarMpi25,2,3>") that the last brk_stencil_apply_* call of the
+ * calling thread enqueued; "" before the first.  Reporting only (bench.py's roofline.kernel); the string is static. */
+const char *brk_last_kernel(void);
 /* radius / number of coefficients / communication-avoiding sweeps per exchange (ST_ITER, fake.h:39-344) */
 int brk_stencil_radius(int stencil_id);
 int brk_stencil_ncoeff(int stencil_id);

@@ -152,7 +152,9 @@ def test_example_driver_runs():
     exe = os.path.join(ROOT, "examples", "single_hip")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
-    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300).stdout.decode()
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]   # an OpenMP-linked driver: a death at exit must not pass unseen
     assert "brick() kernel: result match" in out and "brk_stencil_apply_list: result match" in out, out
     assert "brick() cond kernel: result match" in out, out
     assert "brick() lap19 kernel (script read as data): result match" in out, out   # user-written script, generic tap path
@@ -207,6 +209,34 @@ def test_cpp_weak_driver_one_process_per_rank_under_mpiexec(flags):
     assert msgs == (1 if flags else 0), out
     worst = float(out.split("validation: max |gpu - host| over the subdomains = ")[1].split()[0])
     assert worst <= 1e-12, out
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("flags", [("-d", "64", "-s", "16"), ("-d", "64", "-s", "32", "-c")])
+def test_cpp_strong_driver_one_process_per_rank_under_mpiexec(flags):
+    """examples/strong_hip_mpi.cpp: the reference's strong GPU driver as it is STARTED (strong/main.cu:113-575, strong/args.cpp): a
+    process per rank under mpiexec, -d / -s / -I / -v as parseArgs takes them, the rank's Z-Morton range, one GPU per rank, the RCCL
+    communicator made from MPI_COMM_WORLD (brkCommFromMPI), this rank's pack / unpack tables only and brk_exchange_transport (not
+    the loopback of strong_hip.cpp).  One rank here (one GPU per box): every neighbour is local, aliased (default) or copied by
+    device links (-c).  It must validate (-v) and print the reference's statistics lines (strong/main.cu:548-566)."""
+    import shutil
+    mpiexec = shutil.which("mpiexec") or ("/opt/conda/bin/mpiexec" if os.path.exists("/opt/conda/bin/mpiexec") else None)
+    exe = os.path.join(ROOT, "examples", "strong_hip_mpi")
+    if mpiexec is None or not os.path.exists("/opt/conda/lib/libmpi.so"):
+        pytest.skip("no MPI implementation on this box")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "strong_hip_mpi"])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = "/usr/lib/x86_64-linux-gnu:/opt/conda/lib:" + env.get("LD_LIBRARY_PATH", "")   # system libstdc++ before conda's
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run([mpiexec, "-np", "1", exe, *flags, "-I", "10", "-v"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240, env=env)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out
+    assert "Validated" in out and "INVALID" not in out, out
+    for line in ("Domain size of 64^3 decomposed into", "Bri: ", "calc : [", "pack : [", "call : [", "wait : [", "  | MPI size (MB): ", "perf ", " GStencil/s", "part 0"):
+        assert line in out, (line, out)
+    assert ("local ghosts copied" if "-c" in flags else "local ghosts aliased") in out, out
 
 
 @pytest.mark.gpu

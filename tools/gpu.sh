@@ -3,6 +3,7 @@
 # (`gpurun -- 'bash tools/gpu.sh <recipe> [args]'`); output under gpurun_out/, what is worth keeping is copied to profiles/.
 # Every GPU step runs under its own timeout and a step that was killed stops the script (no retries).
 #   checks [tests|bench|prof|all]   smoke + pytest -m gpu / default bench line / rocprofv3 kernel-trace stats of the same command
+#   census                          ONE run of examples/strong_hip 64 32 8 and of single_hip with BRK_CENSUS=1 (threads by id and name)
 #   evidence <tag>                  end-of-round evidence: default bench line, kernel-trace stats and PMC passes of the same command
 #                                   -> gpurun_out/<tag>/ (bench_default.json, kernel_stats.csv, pmc_summary.txt, pmc_traffic_all.json, ...)
 #   strong                          strong tests + `bench.py --workload strong` with local ghosts aliased / copied + weak 25-pt cycle
@@ -70,8 +71,21 @@ for r in csv.DictReader(open(sys.argv[1] + '/kernel_stats.csv')):
 PY
 }
 
+# ONE run of the strong driver with the thread census switched on (BRK_CENSUS=1: every thread of the process with its id and name at
+# four points of main(), examples/crash_trace.h) -- who owns tid = pid + 1, the thread that died in round 4
+census() {
+  for exe in "strong_hip 64 32 8" "single_hip"; do
+    echo "== BRK_CENSUS=1 examples/$exe"
+    BRK_CENSUS=1 timeout -k 10 240 examples/$exe 2>&1 | grep -v '^rank [1-7]:' ; rc=${PIPESTATUS[0]}
+    echo "== exit status $rc"
+    if killed $rc; then echo killed; exit 1; fi
+  done
+  echo "== LD_PRELOAD=$LD_PRELOAD"
+}
+
 case "$recipe" in
 checks) shift; checks "$@" ;;
+census) census 2>&1 | tee gpurun_out/r05_census.txt ;;
 evidence) shift; evidence "$@" ;;
 kbench) shift; run "$@" 2>&1 | tee gpurun_out/kbench.log ;;
 *) { case "$recipe" in
