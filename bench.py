@@ -233,7 +233,7 @@ def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, 
     r = {"kernel_ms": ms, "kernel_ms_one_way": other if zigzag else ms, "kernel_ms_alternating": ms if zigzag else other,
          "sweep_direction": "alternating" if zigzag else "one way", "GStencil/s": cells / (ms * 1e-3) / 1e9, "launches": launches,
          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                      "frac_of_measured_copy": ach / HBM_COPY_GBS}}
+                      "frac_of_measured_copy": ach / HBM_COPY_GBS, "kernel": bl.last_kernel()}}
     if O is not None:
         r["max_abs_err_vs_oracle"] = verify_sample(bl, O, sid, info, st, sto, step_e, off_out, ids, coeff, nsample=nsample)
     return r

@@ -26,7 +26,7 @@ from ._lib import check, lib
 from .brick import Brick, BrickInfo, BrickStorage, grid_to_device
 from .decomp import SP_RECV, SP_SEND, SP_STORAGE, BrickDecomp, Exchanger, XPlan, exchange_loopback
 from .order import LIST_SKIP, decomp_lists, tiled_scattered
-from .stencils import Zigzag, apply_stencil, stencil_iters
+from .stencils import STENCILS, Zigzag, apply_stencil, stencil_iters
 
 
 def zmort_coords(zid):
@@ -193,7 +193,8 @@ class StrongRank:
         # ghost faces are all aliased is a 16^3 box, all complete; with 8 ranks x 64 subdomains of 128^3 the kept ghost faces make the
         # extents 17 / 18 and only 77 % complete -- the march kernel computes incomplete groups one brick at a time, which costs more
         # than the pairing gains)
-        kp = self.kpair and stencil in ("mpi13pt", "mpi25pt") and self.paired_lists()[2] >= 0.9
+        star = STENCILS.get(stencil, stencil) in (STENCILS["mpi13pt"], STENCILS["mpi25pt"])      # name or id
+        kp = self.kpair and star and self.paired_lists()[2] >= 0.9
         la, ld = self.paired_lists()[:2] if kp else (self.list_all, self.list_domain)
         self.swept_kpaired = bool(kp)
         apply_stencil(stencil, b[0], b[1], ids=la, coeff=coeff, stream=stream, reverse=rev(), kpaired=kp)

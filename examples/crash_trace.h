@@ -187,10 +187,31 @@ inline void handler(int sig, siginfo_t *info, void *uctx) {
 }
 // take the picture of /proc/self/maps again: after the first HIP call, before main returns
 inline void snapshot() { g_maps_late_len = slurp("/proc/self/maps", g_maps_late, kMapsMax); }
+// BRK_CENSUS=2: every other thread is also asked (SIGUSR2 sent to that thread) to print its own call stack, module + offset per
+// frame -- which library's code a runtime thread is sitting in
+inline void stack_on_request(int, siginfo_t *, void *) {
+  say("[census]   thread ");
+  say_dec((long)syscall(SYS_gettid));
+  say(" is in:\n");
+  void *frames[24];
+  const int n = backtrace(frames, 24);
+  backtrace_symbols_fd(frames, n, 2);
+}
 // every thread of this process: id, name (comm); printed only when BRK_CENSUS is set.  Not for use inside the handler.
 inline void census(const char *label) {
   const char *want = getenv("BRK_CENSUS");
   if (!want || !*want || *want == '0') return;
+  const bool stacks = *want == '2';
+  if (stacks) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = stack_on_request;
+    sa.sa_flags = SA_SIGINFO | SA_RESTART;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGUSR2, &sa, nullptr);
+  }
+  long others[8];
+  int nothers = 0;
   fprintf(stderr, "[census] %s: pid %ld;", label, (long)getpid());
   if (DIR *d = opendir("/proc/self/task")) {
     while (struct dirent *e = readdir(d)) {
@@ -200,10 +221,16 @@ inline void census(const char *label) {
       const int n = slurp(path, name, sizeof name);
       if (n > 0 && name[n - 1] == '\n') name[n - 1] = 0;
       fprintf(stderr, " %s=%s", e->d_name, name);
+      if (atol(e->d_name) != (long)getpid() && nothers < 8) others[nothers++] = atol(e->d_name);
     }
     closedir(d);
   }
   fprintf(stderr, "\n");
+  if (stacks && nothers < 8) // (not with the OpenMP team alive: hundreds of threads)
+    for (int q = 0; q < nothers; ++q) {
+      syscall(SYS_tgkill, (long)getpid(), others[q], SIGUSR2);
+      usleep(50000);
+    }
 }
 inline void install() {
   void *warm[2];

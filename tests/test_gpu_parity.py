@@ -330,11 +330,13 @@ def test_strong_cycle_virtual_ranks(oracle, dev, name, ghosts, size):
 def test_strong_aliased_local_ghosts_bit_identical_to_copied(dev, name, size, dom, sdom):
     """two strong cycles with the same-rank ghost runs aliased through the adjacency table against the same cycles with those runs
     copied and swept (the reference's scheme): the subdomain bricks agree BIT for bit on every rank, fewer bricks are swept, and
-    with one rank there is nothing left to exchange"""
+    with one rank there is nothing left to exchange.  Both through the same kernel (plain tiled lists, kpair=False); a third run with
+    the default lists -- k-paired where most groups are complete, i.e. the two-bricks-per-wave march kernel for the stars -- must
+    agree with them to rounding (the march kernel contracts its sums differently: 1 ulp observed)."""
     from bricklib_amd.strong import StrongRank, loopback_transport
     res = {}
-    for alias in (True, False):
-        ranks = [StrongRank(dom, sdom, r, size, dev, alias_local=alias) for r in range(size)]
+    for alias, kpair in ((True, False), (False, False), (True, True)):
+        ranks = [StrongRank(dom, sdom, r, size, dev, alias_local=alias, kpair=kpair) for r in range(size)]
         gen = torch.Generator(device=dev).manual_seed(17)
         for sr in ranks:
             sr.storages[0].dat.copy_(torch.rand(sr.storages[0].dat.shape, dtype=torch.float64, device=dev, generator=gen))
@@ -349,10 +351,16 @@ def test_strong_aliased_local_ghosts_bit_identical_to_copied(dev, name, size, do
                 sr.exchange_end()
                 sr.sweeps(name)
         torch.cuda.synchronize()
-        res[alias] = ([sr.storages[0].dat.view(sr.nsub, sr.nb, 512)[:, 1:sr.d.sep_pos[1]].clone() for sr in ranks],
-                      sum(sr.swept_bricks for sr in ranks), sum(sr.bytes_local for sr in ranks))
-    for a, b in zip(res[True][0], res[False][0]):
+        res[alias, kpair] = ([sr.storages[0].dat.view(sr.nsub, sr.nb, 512)[:, 1:sr.d.sep_pos[1]].clone() for sr in ranks],
+                             sum(sr.swept_bricks for sr in ranks), sum(sr.bytes_local for sr in ranks), any(sr.swept_kpaired for sr in ranks))
+    for a, b in zip(res[True, False][0], res[False, False][0]):
         assert torch.equal(a, b)
+    assert not res[True, False][3] and not res[False, False][3]
+    for a, b in zip(res[True, False][0], res[True, True][0]):
+        assert float((a - b).abs().max()) <= 4e-15
+    if name == "mpi13pt" and size == 1:
+        assert res[True, True][3]          # 128^3 in 32^3 on one rank: every subdomain is a 4^3 box of complete groups
+    res = {True: res[True, False], False: res[False, False]}
     assert res[True][1] < res[False][1] and res[True][2] < res[False][2]      # bytes_local: links + pack + unpack copies
     if size == 1:
         assert res[True][1] == (dom // 8) ** 3 and res[True][2] == 0

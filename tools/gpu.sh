@@ -76,7 +76,7 @@ PY
 census() {
   for exe in "strong_hip 64 32 8" "single_hip"; do
     echo "== BRK_CENSUS=1 examples/$exe"
-    BRK_CENSUS=1 timeout -k 10 240 examples/$exe 2>&1 | grep -v '^rank [1-7]:' ; rc=${PIPESTATUS[0]}
+    BRK_CENSUS=${BRK_CENSUS_LEVEL:-1} timeout -k 10 240 examples/$exe 2>&1 | grep -v '^rank [1-7]:' ; rc=${PIPESTATUS[0]}
     echo "== exit status $rc"
     if killed $rc; then echo killed; exit 1; fi
   done
