@@ -725,16 +725,17 @@ def run_weak(args, bl, dev, rank, world):
         schedule, deep_depth = min(cost, key=cost.get)
     overlap = schedule != "plain"
     state = {}
+    ic = 32 if name == "mpi25pt" else 0     # radius 4: rows of a block in i-chunks of 32 bricks (order.slabs: the k-halo planes stay in L2)
     kp = name in ("mpi13pt", "mpi25pt")     # the stars sweep k-paired lists (two bricks per wave, brk_stencil_apply_list_kpaired: 25-point -12 %, 13-point -1.9 %)
     if schedule == "deep":
-        lists = TrapezoidLists(d, S, dev, kpair=kp)
-        whole = SweepLists(d, dev, kpair=kp)
+        lists = TrapezoidLists(d, S, dev, kpair=kp, icols=ic)
+        whole = SweepLists(d, dev, kpair=kp, icols=ic)
         deep_depth = S if not deep_depth else max(1, min(deep_depth, S))
 
         def step():
             return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=xstream, depth=deep_depth, full=whole, zigzag=args.weak_zigzag)
     else:
-        lists = SweepLists(d, dev, kpair=kp)
+        lists = SweepLists(d, dev, kpair=kp, icols=ic)
 
         def step():
             return weak_cycle(sid, d, A, B, ex.exchange, main=main, comm=xstream, overlap=overlap, lists=lists, state=state, zigzag=args.weak_zigzag)

@@ -195,7 +195,14 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   __shared__ double jslot[KIND == kCube125 && PIPE == 5 ? NW * 192 : 1]; // output-side shift slots, one per wave
   const uint32_t per_xcd = gridDim.x >> 3;
   const uint32_t wg = (blockIdx.x & 7u) * per_xcd + wg_in_xcd(cf, per_xcd);
+#ifdef BRK_STAMP
+  // stamp builds, diagnostic bit 512: the hardware waves of a group take the list entries in REVERSE (hardware wave 0 = right end):
+  // does a straggler at one end of the group follow the wave or the side?  (profiles/r05_c_*)
+  const uint32_t hw_wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t w = (diag & 512) ? NW - 1 - hw_wave : hw_wave;
+#else
   const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#endif
   const uint32_t slot = wg * NW + w;
   const int lane = threadIdx.x & 63;
   const int hi = lane >> 3, lo = lane & 7;

@@ -270,6 +270,103 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dma(
   }
 }
 
+// ---- round 5 experiment: the 125-point kernel at FOUR waves per SIMD (k_cube125_q) --------------------------------------------------
+// What a 16-waves-per-CU form of the output-side kernel needs: <= 128 VGPRs and <= 40 960 B of LDS per 4-wave group (k_cube_dense<kCube125,
+// 4, 3, 5>: 166 VGPRs, 52 240 B).  This is the LEAN form of the fetch phase -- groups of four fully linked i-neighbours only: no break
+// flags, no second phase, the two interior waves gather nothing on their i-sides -- with the shift slots aliased into the wave's own tile
+// (cube125_accumulate_jout<..., ALIASED>).  LAYOUT 0 is a TIMING DIAGNOSTIC: the fallback slot F is aliased onto the tiles of the other end
+// wave, so the instruction stream, the LDS footprint (36 864 B) and the bank behaviour are those of the real kernel but the halo columns of
+// the group's two ends are wrong.  It answers "what is a fourth wave per SIMD worth" before the exact 40 960-byte layout is built.
+template <int OCC, int LAYOUT>
+__global__ __launch_bounds__(256, OCC) void k_cube125_q(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
+                                                        size_t step, const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
+  constexpr int R = 2, NW = 4;
+  using TL = DenseTile<kCube125>;
+  using X = DX<kCube125>;
+  constexpr int E = TL::ELEMS;
+  __shared__ double lds[NW * E];
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) d2 *gc2;
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + wg_in_xcd(cf, per_xcd);
+  const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t slot = wg * NW + w;
+  const int lane = threadIdx.x & 63;
+  const int hi = lane >> 3, lo = lane & 7;
+  const int l5 = lane & 31, lp = lane >> 5;
+  double *tile = lds + w * E;
+  double *left = w == 0 ? lds + (NW - 1) * E : tile - E;   // LAYOUT 0: the left end's slot is the last tile (wrong data, right traffic)
+  const int roff = w == NW - 1 ? -(NW - 1) * E : E;
+  double *right = tile + roff;
+  const uint32_t b = slot < n ? __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot) : BRK_LIST_SKIP;
+  if (b == BRK_LIST_SKIP) { // experiment: full groups only
+    __syncthreads();
+    return;
+  }
+  const int l27 = lane < 27 ? lane : 13;
+  const uint32_t arow = adj[(size_t)b * 27 + l27];
+  const gcptr self = sbase(in + (size_t)b * step);
+  d2 own2[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) own2[q] = *(gc2)(self + q * 128 + 2 * lane);
+  __builtin_amdgcn_sched_barrier(0);
+  const gcptr p_km = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(-1, 0, 0)) * step);
+  const gcptr p_kp = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(1, 0, 0)) * step);
+  const gcptr p_jm = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, -1, 0)) * step);
+  const gcptr p_jp = sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 1, 0)) * step);
+  const d2 km2 = *(gc2)(p_km + 6 * 64 + 2 * lane), kp2 = *(gc2)(p_kp + 2 * lane);
+  const d2 jm2 = *(gc2)(p_jm + hi * 64 + 48 + 2 * lo), jp2 = *(gc2)(p_jp + hi * 64 + 2 * lo);
+  // descriptors of the edge / corner pairs: quad 0 = {own kj-edges, left 0, left 1, right 0}, quad 1 = {right 1}
+  const uint4 *xt = reinterpret_cast<const uint4 *>(dense_table<kCube125>());
+  static_assert(X::IT0 == 1 && X::ITS == 2, "descriptor layout of the radius-2 cube");
+  const uint4 q0 = xt[lane];
+  auto gather = [&](uint32_t d) -> d2 {
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((d >> 16) & 31u) << 2), (int)arow);
+    return d != 0xFFFFFFFFu ? *(const d2 *)(in + (size_t)nb * step + ((d >> 21) & 511u)) : d2{0.0, 0.0};
+  };
+  const d2 g0 = gather(q0.x);
+  // the group's two end waves: the i-face columns and the i-side edge / corner pairs of that side (uniform branch per wave)
+  d2 side = {0.0, 0.0}, gs0 = {0.0, 0.0}, gs1 = {0.0, 0.0};
+  uint32_t ds0 = 0xFFFFFFFFu, ds1 = 0xFFFFFFFFu;
+  if (w == 0) {
+    side = *(gc2)(sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 0, -1)) * step) + hi * 64 + lo * 8 + 6);
+    ds0 = q0.y, ds1 = q0.z;
+    gs0 = gather(ds0), gs1 = gather(ds1);
+  } else if (w == NW - 1) {
+    side = *(gc2)(sbase(in + (size_t)__builtin_amdgcn_readlane(arow, adj_slot(0, 0, 1)) * step) + hi * 64 + lo * 8);
+    ds0 = q0.w, ds1 = xt[64 + lane].x;
+    gs0 = gather(ds0), gs1 = gather(ds1);
+  }
+  // ---- stage
+#pragma unroll
+  for (int q = 0; q < 4; ++q) *(d2 *)&tile[TL::at(2 * q + lp + R, (l5 >> 2) + R, 2 * (l5 & 3))] = own2[q];
+  *(d2 *)&tile[TL::at(lp, (l5 >> 2) + R, 2 * (l5 & 3))] = km2;
+  *(d2 *)&tile[TL::at(R + 8 + lp, (l5 >> 2) + R, 2 * (l5 & 3))] = kp2;
+  *(d2 *)&tile[TL::at(hi + R, 0, 0) + 2 * lo] = jm2;
+  *(d2 *)&tile[TL::at(hi + R, R + 8, 0) + 2 * lo] = jp2;
+  if (q0.x != 0xFFFFFFFFu) *(d2 *)&tile[q0.x & 0xFFFFu] = g0;
+  if (w == 0) {
+    *(d2 *)&left[TL::at(hi + R, lo + R, 8 - R)] = side;
+    if (ds0 != 0xFFFFFFFFu) *(d2 *)&left[ds0 & 0xFFFFu] = gs0;
+    if (ds1 != 0xFFFFFFFFu) *(d2 *)&left[ds1 & 0xFFFFu] = gs1;
+  } else if (w == NW - 1) {
+    *(d2 *)&right[TL::at(hi + R, lo + R, 0)] = side;
+    if (ds0 != 0xFFFFFFFFu) *(d2 *)&right[ds0 & 0xFFFFu] = gs0;
+    if (ds1 != 0xFFFFFFFFu) *(d2 *)&right[ds1 & 0xFFFFu] = gs1;
+  }
+  __syncthreads();
+  __builtin_amdgcn_sched_barrier(0);
+  gptr dst = (gptr)(out + (size_t)b * step);
+  asm volatile("" : "+s"(dst));
+  int co[5];
+#pragma unroll
+  for (int di = -R; di <= R; ++di) {
+    const int c = lo + di;
+    co[di + R] = c < 0 ? (int)(left - tile) + c + 8 : (c > 7 ? roff + c - 8 : c);
+  }
+  cube125_accumulate_jout<TL::T * 8, 8, true>(tile, co, cf, tile, (double *)dst, lane);
+}
+
 #elif BRK_VARIANTS_PART == 2
 // inside launch_cube_dense (BRK_CD, wgs4, x2 are defined there): early returns for the variants
   if (variant == 15 && linkmask && cubereg.faces) { // registered tables: the LDS-DMA staged kernels (slower; see k_cube_dma)
@@ -283,6 +380,13 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dma(
     else if (stencil_id == BRK_27PT_COEFF) BRK_CDMA(kCube27, 4, 5, 1);
     else BRK_CDMA(kCube125, 4, 3, 5);
 #undef BRK_CDMA
+    HIP_TRY(hipGetLastError());
+    return BRK_OK;
+  }
+  if (stencil_id == BRK_MPI125 && (variant == 16 || variant == 17)) { // round-5 experiment: the lean 125-point kernel at 4 / 3 waves per SIMD (timing diagnostic, wrong i-ends)
+    brk_note_kernel(variant == 16 ? "k_cube125_q<4,0>" : "k_cube125_q<3,0>");
+    if (variant == 16) hipLaunchKernelGGL((k_cube125_q<4, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    else hipLaunchKernelGGL((k_cube125_q<3, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
     HIP_TRY(hipGetLastError());
     return BRK_OK;
   }

@@ -281,7 +281,7 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
   if (id == BRK_MPI7_X2 || id == BRK_7PT_X2) return launch_cube_dense(id, var, adj, in, out, step, ids, first, n, cf, st, lmask, cubereg);
   if (id == BRK_27PT_COEFF || id == BRK_MPI125) {
     const int v = var;
-    if (v == 0 || (v >= 5 && v <= 15)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st, lmask, cubereg);
+    if (v == 0 || (v >= 5 && v <= 19)) return launch_cube_dense(id, v, adj, in, out, step, ids, first, n, cf, st, lmask, cubereg);
     if ((id == BRK_27PT_COEFF && v == 2) || (id == BRK_MPI125 && (v == 2 || v == 4 || v == 8)))
       return launch_cube_wg(id, id == BRK_MPI125 ? v : 8, adj, in, out, step, ids, first, n, cf, st);
   }
@@ -398,11 +398,17 @@ void reap_retired_locked() {
 // rows_per_block: j-rows of an XCD slab swept over all k before the next block (the distance between the two uses of a k-face).
 // kpair: the k-paired order of k_star_kp -- inside a block two k-levels at a time, every run of 4 i-neighbours at k followed by the
 // same run at k+1 (rows padded to multiples of 4 entries; an odd last level is paired with skipped entries)
+// icols (k-paired lists only; 0 = whole rows): the rows of a block are cut along i into chunks of icols bricks (a multiple of 4) and each
+// chunk is swept over all k before the next.  A k-paired block of 8 rows x 64 bricks moves 4 MiB per pair of levels -- the whole L2 of an
+// XCD -- between the request of a brick's planes as the k-halo of the pair below and their request as the brick itself; chunks of 32
+// bricks halve that distance without fewer rows per block (which costs j-face sharing).  Measured for the radius-4 star at 512^3
+// (profiles/r05_d_*): fabric reads 1.80 -> 1.32 GB per sweep, 0.4422 -> 0.4356 ms; the radius-2 star loses (0.3771 -> 0.3853 ms).
 int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], uint32_t rows_per_block, bool kpair,
-                    BoxList **entry) {
+                    uint32_t icols, BoxList **entry) {
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
-  const uint32_t key[12] = {(uint32_t)device, base, tot[0], tot[1], tot[2], lo[0], lo[1], lo[2], cnt[0], cnt[1], cnt[2], rows_per_block | (kpair ? 0x100u : 0u)};
+  if (!kpair || icols >= cnt[0]) icols = 0;
+  const uint32_t key[12] = {(uint32_t)device, base, tot[0], tot[1], tot[2], lo[0], lo[1], lo[2], cnt[0], cnt[1], cnt[2], rows_per_block | (kpair ? 0x100u : 0u) | (icols << 16)};
   int victim = 0;
   for (int q = 0; q < kBoxCache; ++q) {
     if (g_box[q].dev && std::memcmp(g_box[q].key, key, sizeof key) == 0) {
@@ -421,23 +427,25 @@ int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], 
     if (rowlen != ni) v.push_back(BRK_LIST_SKIP);
   };
   // two k-levels of one row interleaved in runs of 4: [i..i+3 at k][i..i+3 at k+1]; k1 == nk: the upper level does not exist
-  auto push_row_pair = [&](std::vector<uint32_t> &v, uint32_t k0, uint32_t k1, uint32_t j) {
-    for (uint32_t i0 = 0; i0 < ni; i0 += 4)
+  auto push_row_pair = [&](std::vector<uint32_t> &v, uint32_t k0, uint32_t k1, uint32_t j, uint32_t ia, uint32_t ib) {
+    for (uint32_t i0 = ia; i0 < ib; i0 += 4)
       for (uint32_t k : {k0, k1})
         for (uint32_t i = i0; i < i0 + 4; ++i) v.push_back(i < ni && k < nk ? id_at(k, j, i) : BRK_LIST_SKIP);
   };
+  const uint32_t chunk = icols ? (icols + 3) / 4 * 4 : (ni + 3) / 4 * 4; // k-paired lists: bricks of a row per chunk
   for (uint32_t x = 0; x < 8; ++x) {
     for (uint32_t j0 = x * jbase; j0 < (x + 1) * jbase; j0 += rows_per_block)
-      for (uint32_t k = 0; k < nk; k += kpair ? 2 : 1)
-        for (uint32_t j = j0; j < j0 + rows_per_block && j < (x + 1) * jbase; ++j) {
-          if (kpair) push_row_pair(part[x], k, k + 1, j);
-          else push_row(part[x], k, j);
-        }
+      for (uint32_t ia = 0; ia < (kpair ? ni : 1u); ia += chunk)
+        for (uint32_t k = 0; k < nk; k += kpair ? 2 : 1)
+          for (uint32_t j = j0; j < j0 + rows_per_block && j < (x + 1) * jbase; ++j) {
+            if (kpair) push_row_pair(part[x], k, k + 1, j, ia, ia + chunk < ni ? ia + chunk : ni);
+            else push_row(part[x], k, j);
+          }
     if (rem) {
       const uint32_t ka = (uint32_t)((uint64_t)nk * x / 8), kb = (uint32_t)((uint64_t)nk * (x + 1) / 8);
       for (uint32_t k = ka; k < kb; k += kpair ? 2 : 1)
         for (uint32_t j = nj - rem; j < nj; ++j) {
-          if (kpair) push_row_pair(part[x], k, k + 1 < kb ? k + 1 : nk, j);
+          if (kpair) push_row_pair(part[x], k, k + 1 < kb ? k + 1 : nk, j, 0, ni);
           else push_row(part[x], k, j);
         }
     }
@@ -823,7 +831,7 @@ extern "C" int brk_stencil_apply_box_ex(int id, const uint32_t *adj, const doubl
   // 3.18 -> 2.53 GB per 512^3 sweep) but the sweep takes 0.500-0.508 ms instead of 0.493-0.495: the extra reads are served by the
   // Infinity Cache and are not what bounds the kernel, the shorter rows-in-flight window is (profiles/r03_d_25pt_rows_per_block.txt).
   const bool kpair = id == BRK_MPI25 || id == BRK_MPI13; // the stars march two k-consecutive bricks per wave over k-paired lists (k_star_km, brk_starwg.hip)
-  if (int rc = box_list_locked(base, tot, lo, cnt, 8u, kpair, &e)) return rc;
+  if (int rc = box_list_locked(base, tot, lo, cnt, 8u, kpair, id == BRK_MPI25 ? 32u : 0u, &e)) return rc; // radius 4: i-chunks of 32 bricks (see box_list_locked)
   const uint32_t strides[2] = {tot[0], tot[0] * tot[1]};
   if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s, kpair, reverse, strides)) return rc;
   HIP_TRY(hipEventRecord(e->last_use, static_cast<hipStream_t>(s)));

@@ -166,7 +166,10 @@ namespace {
 // source of re-read traffic cost?): 1 = face neighbours by arithmetic on the lexicographic numbering, the adjacency row is not read;
 // 2 = the j-faces of the two rows per XCD slab whose neighbour row belongs to another XCD are read from the brick itself;
 // 4 = every j-face from the brick itself; 8 = every k-face from the brick itself
-template <int MPI, int NW, int MODE, int DIAG = 0>
+// IDPP (round-5 experiment, `make VARIANTS=1` builds only; the shipped instantiations have IDPP = 0): the +-i neighbours of the own plane
+// come from the lane's neighbours by DPP (row_shr:1 / row_shl:1 on the two halves of the double) instead of two tile reads; only the
+// lanes on an i-edge read the tile (ONE combined read per plane: lo == 0 from the left sibling / fallback slot, lo == 7 from the right).
+template <int MPI, int NW, int MODE, int DIAG = 0, int IDPP = 0>
 __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uint32_t *__restrict__ adj,
                                                                       const double *__restrict__ in,
                                                                       double *__restrict__ out, size_t step,
@@ -283,11 +286,23 @@ __global__ __launch_bounds__(64 * NW, (24 / NW) * NW / 4) void k_s7_wg(const uin
   const int o_jm = hi * 8 + lo, o_jp = (hi + 2) * 8 + lo;
   const int o_im = lo > 0 ? (hi + 1) * 8 + lo - 1 : (share_im ? -kTile + (hi + 1) * 8 + 7 : 80 + hi);
   const int o_ip = lo < 7 ? (hi + 1) * 8 + lo + 1 : (share_ip ? kTile + (hi + 1) * 8 : 88 + hi);
+  const int o_edge = lo == 0 ? o_im : o_ip; // IDPP: the one tile read of an i-edge lane (interior lanes read a neighbour cell and drop it)
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const double jm = tile[k * kPlane + o_jm], jp = tile[k * kPlane + o_jp];
-    const double im = tile[k * kPlane + o_im], ip = tile[k * kPlane + o_ip];
     const double c0 = f.own[k];
+    double im, ip;
+    if (IDPP) {
+      const double edge = tile[k * kPlane + o_edge];
+      const int c_lo = __double2loint(c0), c_hi = __double2hiint(c0);
+      // row_shr:1 (0x111): lane L takes lane L - 1 of its 16-lane row; row_shl:1 (0x101): lane L + 1
+      const double dm = __hiloint2double(__builtin_amdgcn_update_dpp(0, c_hi, 0x111, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, c_lo, 0x111, 0xF, 0xF, false));
+      const double dp = __hiloint2double(__builtin_amdgcn_update_dpp(0, c_hi, 0x101, 0xF, 0xF, false), __builtin_amdgcn_update_dpp(0, c_lo, 0x101, 0xF, 0xF, false));
+      im = lo == 0 ? edge : dm;
+      ip = lo == 7 ? edge : dp;
+    } else {
+      im = tile[k * kPlane + o_im], ip = tile[k * kPlane + o_ip];
+    }
     const double km = k == 0 ? f.km : f.own[k > 0 ? k - 1 : 0];
     const double kp = k == 7 ? f.kp : f.own[k < 7 ? k + 1 : 7];
     double res;

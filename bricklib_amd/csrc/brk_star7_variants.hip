@@ -339,6 +339,18 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_s7_km(const uint32_t *__restri
     else if (kind == kCond) BRK_LAUNCH_2T(kCond);
     else BRK_LAUNCH_2T(kCoeff);
 #undef BRK_LAUNCH_2T
+  } else if (variant == 13) { // round 5: the default kernel with the +-i neighbours by DPP (k_s7_wg<..., IDPP = 1>), list / range form
+    const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
+#define BRK_LAUNCH_DPP(K)                                                                                                                                     \
+  do {                                                                                                                                                        \
+    if (ids) hipLaunchKernelGGL((k_s7_wg<K, 8, kModeList, 0, 1>), dim3(wgs), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf, nullptr, faces); \
+    else hipLaunchKernelGGL((k_s7_wg<K, 8, kModeRange, 0, 1>), dim3(wgs), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf, nullptr, faces);   \
+  } while (0)
+    brk_note_kernel("k_s7_wg<.,8,.,0,IDPP=1>");
+    if (kind == kMpi) BRK_LAUNCH_DPP(kMpi);
+    else if (kind == kCond) BRK_LAUNCH_DPP(kCond);
+    else BRK_LAUNCH_DPP(kCoeff);
+#undef BRK_LAUNCH_DPP
   } else if (variant == 6) {
     const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
     BRK_LAUNCH_WG_W(4);

@@ -20,9 +20,9 @@ class SweepLists:
     the module docstring, but in the cache-friendly order of bricklib_amd.order).  kpair: the k-paired order (two bricks per
     wave for the 25-point star, brk_stencil_apply_list_kpaired); the sweeps below read it from `kpaired`."""
 
-    def __init__(self, d, device, rows_per_block=8, kpair=False):
+    def __init__(self, d, device, rows_per_block=8, kpair=False, icols=0):
         self.kpaired = bool(kpair)
-        for name, ids in decomp_lists(d, rows_per_block, kpair=kpair).items():
+        for name, ids in decomp_lists(d, rows_per_block, kpair=kpair, icols=icols).items():
             setattr(self, name, grid_to_device(ids, device))
 
 
@@ -86,9 +86,9 @@ def weak_cycle(stencil, d, A, B, exchange, coeff=None, main=None, comm=None, ove
 class TrapezoidLists:
     """Device-resident lists of bricklib_amd.order.trapezoid_lists for `sweeps` sweeps per exchange."""
 
-    def __init__(self, d, sweeps, device, rows_per_block=8, kpair=False):
+    def __init__(self, d, sweeps, device, rows_per_block=8, kpair=False, icols=0):
         self.kpaired = bool(kpair)
-        inner, shell = trapezoid_lists(d, sweeps, rows_per_block, kpair=kpair)
+        inner, shell = trapezoid_lists(d, sweeps, rows_per_block, kpair=kpair, icols=icols)
         self.inner = [grid_to_device(x, device) if x.size else None for x in inner]
         self.shell = [grid_to_device(x, device) if x.size else None for x in shell]
 

@@ -31,25 +31,32 @@ def _pair_levels(ids3):
     return np.ascontiguousarray(p.transpose(0, 2, 3, 1, 4)).reshape(nk2 // 2, nj, 2 * ni4)
 
 
-def slabs(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True, kpair=False):
+def slabs(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True, kpair=False, icols=0):
     """Per-XCD pieces of the tiled order of `ids3` ([nk][nj][ni] brick ids): XCD x gets its own slab of nj // nxcd
     j-rows, swept in blocks of <= rows_per_block rows over all k, i fastest; the nj % nxcd left-over rows are cut along k
     instead, one k-range per XCD, so that every XCD gets the same amount of work (66 rows: 8 each + 2 rows x 1/8 of the
     planes, instead of two XCDs with 9 rows setting the pace).  pad_rows: a row whose length is not a multiple of 8 gets ONE LIST_SKIP entry
     behind it, so that two rows never meet inside a workgroup without an idle wave between them (the kernels park
-    fallback halos in an idle wave's LDS slot; two active non-neighbours side by side cost a second phase)."""
+    fallback halos in an idle wave's LDS slot; two active non-neighbours side by side cost a second phase).
+    icols (k-paired lists; 0 = whole rows): the rows of a block are cut along i into chunks of icols bricks (a multiple of 4), each swept
+    over all k before the next -- the distance between the request of a brick's planes as the k-halo of the pair below and as the brick
+    itself halves (4 MiB = the L2 of an XCD for 8 rows x 64 bricks x 2 levels) without fewer rows per block.  Pays for the radius-4 star
+    (512^3: fabric reads 1.80 -> 1.32 GB, 0.4422 -> 0.4356 ms), not for the radius-2 star (brk_kernels.hip: box_list_locked)."""
     ids3 = np.asarray(ids3).astype(np.uint32)
+    ni_bricks = ids3.shape[2]
     if kpair:   # every entry of the "k" axis now stands for a pair of levels; rows are multiples of 8 entries (no padding entry needed)
         ids3 = _pair_levels(ids3)
         pad_rows = False
+    chunk = 2 * ((icols + 3) // 4 * 4) if (kpair and 0 < icols < ni_bricks) else 0      # entries of a paired row per chunk
     nk, nj, ni = ids3.shape
     if pad_rows and ni % 8:
         ids3 = np.concatenate([ids3, np.full((nk, nj, 1), LIST_SKIP, dtype=np.uint32)], axis=2)
     base, rem = divmod(nj, nxcd)
     out = []
     for x in range(nxcd):
-        parts = [np.ascontiguousarray(ids3[:, j0:min(j0 + rows_per_block, (x + 1) * base), :]).reshape(-1)
-                 for j0 in range(x * base, (x + 1) * base, rows_per_block)]
+        width = ids3.shape[2]                      # entries per row (with its padding entry, if any)
+        parts = [np.ascontiguousarray(ids3[:, j0:min(j0 + rows_per_block, (x + 1) * base), c0:c0 + (chunk or width)]).reshape(-1)
+                 for j0 in range(x * base, (x + 1) * base, rows_per_block) for c0 in range(0, width, chunk or width)]
         if rem:
             k0, k1 = (nk * x) // nxcd, (nk * (x + 1)) // nxcd
             parts.append(np.ascontiguousarray(ids3[k0:k1, nj - rem:, :]).reshape(-1))
@@ -74,10 +81,10 @@ def chunks(ids, nxcd=NXCD):
     return [ids[x * per:(x + 1) * per] for x in range(nxcd)]
 
 
-def tiled(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True, kpair=False):
+def tiled(ids3, rows_per_block=8, nxcd=NXCD, pad_rows=True, kpair=False, icols=0):
     """Flat tiled list of `ids3` ([nk][nj][ni] brick ids), see slabs()/assemble().  kpair: the k-paired order for
-    apply_stencil(..., kpaired=True) -- same bricks, runs of 4 i-neighbours at k followed by the same run at k+1."""
-    return assemble(slabs(ids3, rows_per_block, nxcd, pad_rows, kpair), nxcd=nxcd)
+    apply_stencil(..., kpaired=True) -- same bricks, runs of 4 i-neighbours at k followed by the same run at k+1; icols: see slabs()."""
+    return assemble(slabs(ids3, rows_per_block, nxcd, pad_rows, kpair, icols), nxcd=nxcd)
 
 
 def tiled_scattered(ids, gi, gj, gk, rows_per_block=8, nxcd=NXCD, kpair=False):
@@ -125,14 +132,14 @@ def _box(grid, lo, hi):
     return grid[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]
 
 
-def shell_list(g, lo, hi, ilo, ihi, rows_per_block=8, kpair=False):
+def shell_list(g, lo, hi, ilo, ihi, rows_per_block=8, kpair=False, icols=0):
     """Tiled list of the bricks of box [lo,hi) of the logical grid `g` that are outside box [ilo,ihi): two k-slabs in the
     per-XCD slab order, the four j/i side walls row by row (kpair: the slabs in the k-paired order; the walls stay plain
     rows, which a k-paired sweep computes as unpaired entries)."""
     if any(ihi[a] <= ilo[a] for a in range(3)):
-        return tiled(_box(g, lo, hi), rows_per_block, kpair=kpair)
-    klo = slabs(_box(g, lo, [hi[0], hi[1], ilo[2]]), rows_per_block, kpair=kpair)
-    khi = slabs(_box(g, [lo[0], lo[1], ihi[2]], hi), rows_per_block, kpair=kpair)
+        return tiled(_box(g, lo, hi), rows_per_block, kpair=kpair, icols=icols)
+    klo = slabs(_box(g, lo, [hi[0], hi[1], ilo[2]]), rows_per_block, kpair=kpair, icols=icols)
+    khi = slabs(_box(g, [lo[0], lo[1], ihi[2]], hi), rows_per_block, kpair=kpair, icols=icols)
     rest = [_box(g, [lo[0], lo[1], ilo[2]], [hi[0], ilo[1], ihi[2]]),        # j-low / j-high
             _box(g, [lo[0], ihi[1], ilo[2]], [hi[0], hi[1], ihi[2]]),
             _box(g, [lo[0], ilo[1], ilo[2]], [ilo[0], ihi[1], ihi[2]]),      # i-low / i-high
@@ -141,7 +148,7 @@ def shell_list(g, lo, hi, ilo, ihi, rows_per_block=8, kpair=False):
     return assemble(klo, khi, chunks(rest))
 
 
-def decomp_lists(d, rows_per_block=8, kpair=False):
+def decomp_lists(d, rows_per_block=8, kpair=False, icols=0):
     """Brick lists for the weak/strong sweep schedule of a BrickDecomp `d` (see drivers.weak_cycle), all in the geometric
     (logical-grid) tiled order -- i fastest across ghost / surface / inner bricks alike, so runs of i-neighbours share
     halos whatever their ids are:
@@ -156,15 +163,15 @@ def decomp_lists(d, rows_per_block=8, kpair=False):
     lo1, hi1 = [gb] * 3, [T[a] - gb for a in range(3)]
     lo2, hi2 = [2 * gb] * 3, [T[a] - 2 * gb for a in range(3)]
     has_inner = all(hi2[a] > lo2[a] for a in range(3))
-    inner = tiled(_box(g, lo2, hi2), rows_per_block, kpair=kpair) if has_inner else np.zeros(0, dtype=np.uint32)
+    inner = tiled(_box(g, lo2, hi2), rows_per_block, kpair=kpair, icols=icols) if has_inner else np.zeros(0, dtype=np.uint32)
     assert (inner != LIST_SKIP).sum() == d.sep_pos[0] - 1
-    return {"inner": inner, "shell": shell_list(g, lo0, hi0, lo2, hi2, rows_per_block, kpair),
-            "surface": shell_list(g, lo1, hi1, lo2, hi2, rows_per_block, kpair),
-            "all": tiled(_box(g, lo0, hi0), rows_per_block, kpair=kpair),
-            "domain": tiled(_box(g, lo1, hi1), rows_per_block, kpair=kpair)}
+    return {"inner": inner, "shell": shell_list(g, lo0, hi0, lo2, hi2, rows_per_block, kpair, icols),
+            "surface": shell_list(g, lo1, hi1, lo2, hi2, rows_per_block, kpair, icols),
+            "all": tiled(_box(g, lo0, hi0), rows_per_block, kpair=kpair, icols=icols),
+            "domain": tiled(_box(g, lo1, hi1), rows_per_block, kpair=kpair, icols=icols)}
 
 
-def trapezoid_lists(d, sweeps, rows_per_block=8, kpair=False):
+def trapezoid_lists(d, sweeps, rows_per_block=8, kpair=False, icols=0):
     """Brick lists for the deep-overlap schedule of drivers.weak_cycle_deep.  With L(b) = distance of brick b from the
     outside of the ghosted grid in bricks (ghost ring: 0, surface: 1, ...), sweep t = 1..sweeps is split into
         inner[t-1] -- bricks with L >= t+1: they depend on nothing the exchange delivers (the dependence cone of the
@@ -181,6 +188,6 @@ def trapezoid_lists(d, sweeps, rows_per_block=8, kpair=False):
         ilo = [t + 1] * 3
         ihi = [T[a] - t - 1 for a in range(3)]
         has = all(ihi[a] > ilo[a] for a in range(3))   # False: the cone has closed, everything waits for the exchange
-        inner.append(tiled(_box(g, ilo, ihi), rows_per_block, kpair=kpair) if has else np.zeros(0, dtype=np.uint32))
-        shell.append(shell_list(g, lo, hi, ilo, ihi, rows_per_block, kpair))
+        inner.append(tiled(_box(g, ilo, ihi), rows_per_block, kpair=kpair, icols=icols) if has else np.zeros(0, dtype=np.uint32))
+        shell.append(shell_list(g, lo, hi, ilo, ihi, rows_per_block, kpair, icols))
     return inner, shell

@@ -565,7 +565,12 @@ __device__ __forceinline__ void cube125_jout_stream(const double *rowp, const in
   }
 }
 
-template <int PS, int RS>
+// ALIASED: the shift slots are not memory of their own but columns 2..5 of planes 0..3 of the wave's OWN tile (`slot` = tile): those
+// columns are read by no other wave (neighbours read columns 0, 1 / 6, 7 only) and this wave has finished with planes 0..3 -- halo
+// pass first, main-pass planes in order -- before output 0 is emitted behind plane 4.  Slot (row r, column c) -> plane c / 4 (s1) or
+// 2 + c / 4 (s2), row r, column 2 + c % 4; every plane and tile starts at a multiple of 32 doubles, so lanes c and c + 4 of a row
+// meet in one bank (2-way conflict on the 4 + 4 shift accesses per output): the price of 6 KiB of LDS per group.
+template <int PS, int RS, bool ALIASED = false>
 __device__ __forceinline__ void cube125_accumulate_jout(const double *tile, const int (&co)[5], const Coeffs &cf, double *slot,
                                                         double *dst, int lane) {
   const int hi = lane >> 3, lo = lane & 7;
@@ -577,7 +582,7 @@ __device__ __forceinline__ void cube125_accumulate_jout(const double *tile, cons
                                           asm volatile("" : "+v"(b1), "+v"(b2)); // computed here, by all lanes, not sunk into the half-wave branch that uses it
                                           h1[k] = b1, h2[k] = b2;
                                         });
-  double *s1 = slot + lo, *s2 = slot + 96 + lo;
+  double *s1 = ALIASED ? slot + (lo >> 2) * PS + 2 + (lo & 3) : slot + lo, *s2 = ALIASED ? s1 + 2 * PS : slot + 96 + lo;
   double pb0 = 0.0, r[4] = {0.0, 0.0, 0.0, 0.0};
   auto retire = [&](int k) __attribute__((always_inline)) { store_result(&dst[k * 64 + lane], pb0 + ((r[0] + r[1]) + (r[2] + r[3]))); };
   cube125_jout_stream<PS, RS, 12, true>(tile + (hi + 2) * RS, co, cf, [&](int k, double b0, double b1, double b2) __attribute__((always_inline)) {

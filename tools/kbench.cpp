@@ -200,6 +200,7 @@ int main(int argc, char **argv) {
   int N = 512, sid = BRK_7PT_COEFF, iters = 30, order = 0, kstack = 1, rounds = 2;
   bool decomp = false, shuffle = false, separate = false, stream = false, boxmode = false, reg = false, kpair = false, jpair = false, zigzag = false;
   long run = 4, nlev = 2; // -P / -J: entries per run; -P: k-levels per group (-K)
+  long ichunk = 0;        // -C: with -o, a block of rows is cut along i into chunks of this many bricks, each swept over all k before the next
   bool one_alloc = false;
   int trials = 0;
   bool trial_copy = false, placed = false, declare_kpaired = false;
@@ -221,6 +222,7 @@ int main(int argc, char **argv) {
     else if (o == "-P") kpair = true;      // with -o: k-paired order -- runs of 4 i-neighbours at k followed by the same run at k+1 (k_star_kp)
     else if (o == "-J") jpair = true;      // with -o: j-paired order -- runs of i-neighbours of row j followed by the same run of row j+1
     else if (o == "-G") run = atol(argv[++a]); // with -P / -J: entries per run (4 or 8)
+    else if (o == "-C") ichunk = atol(argv[++a]); // with -o (plain and -P orders): i-chunks of this many bricks (a multiple of 8) -- the distance between the two uses of a k-plane shrinks without giving up rows per block
     else if (o == "-K") nlev = atol(argv[++a]); // with -P: k-levels per group (2 = pairs, 4 = the k-stacked order of k_star_km)
     else if (o == "-R") reg = true;        // brk_adjacency_register: the table is promised immutable
     else if (o == "-Z") zigzag = true;     // list form: every other launch walks each XCD's share of the list backwards (groups of 8 kept)
@@ -280,14 +282,16 @@ int main(int argc, char **argv) {
       // XCD x gets rows [x*NB/8, (x+1)*NB/8); inside: blocks of `order` rows swept over all k (k-reuse distance =
       // order*NB bricks), i fastest
       const long rows = NB / 8;
+      const long ic = ichunk > 0 ? ichunk : NB;
       if (kpair) {
         for (long x = 0; x < 8; ++x)
           for (long jb = 0; jb < rows; jb += order)
-            for (long k = 1; k < SB - 1; k += nlev)
-              for (long j = x * rows + jb; j < x * rows + jb + order && j < (x + 1) * rows; ++j)
-                for (long ib = 1; ib < SB - 1; ib += run)
-                  for (long s2 = 0; s2 < nlev; ++s2)
-                    for (long i = ib; i < ib + run; ++i) ids.push_back(k + s2 < SB - 1 && i < SB - 1 ? grid[((k + s2) * SB + (j + 1)) * SB + i] : BRK_LIST_SKIP);
+            for (long i0 = 1; i0 < SB - 1; i0 += ic)
+              for (long k = 1; k < SB - 1; k += nlev)
+                for (long j = x * rows + jb; j < x * rows + jb + order && j < (x + 1) * rows; ++j)
+                  for (long ib = i0; ib < i0 + ic && ib < SB - 1; ib += run)
+                    for (long s2 = 0; s2 < nlev; ++s2)
+                      for (long i = ib; i < ib + run; ++i) ids.push_back(k + s2 < SB - 1 && i < SB - 1 ? grid[((k + s2) * SB + (j + 1)) * SB + i] : BRK_LIST_SKIP);
       } else if (jpair) {
         for (long x = 0; x < 8; ++x)
           for (long jb = 0; jb < rows; jb += order)
@@ -300,11 +304,12 @@ int main(int argc, char **argv) {
       } else
       for (long x = 0; x < 8; ++x)
         for (long jb = 0; jb < rows; jb += order)
-          for (long k = 1; k < SB - 1; k += kstack)
-            for (long j = x * rows + jb; j < x * rows + jb + order && j < (x + 1) * rows; ++j)
-              for (long ib = 1; ib < SB - 1; ib += 8)
-                for (long s2 = 0; s2 < kstack; ++s2)
-                  for (long i = ib; i < ib + 8; ++i) ids.push_back(grid[((k + s2) * SB + (j + 1)) * SB + i]);
+          for (long i0 = 1; i0 < SB - 1; i0 += ic)
+            for (long k = 1; k < SB - 1; k += kstack)
+              for (long j = x * rows + jb; j < x * rows + jb + order && j < (x + 1) * rows; ++j)
+                for (long ib = i0; ib < i0 + ic && ib < SB - 1; ib += 8)
+                  for (long s2 = 0; s2 < kstack; ++s2)
+                    for (long i = ib; i < ib + 8; ++i) ids.push_back(grid[((k + s2) * SB + (j + 1)) * SB + i]);
     }
     nlist = (uint32_t)ids.size();
     step = separate ? 512 : 1024;
