@@ -277,10 +277,10 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dma(
 // (cube125_accumulate_jout<..., ALIASED>).  LAYOUT 0 is a TIMING DIAGNOSTIC: the fallback slot F is aliased onto the tiles of the other end
 // wave, so the instruction stream, the LDS footprint (36 864 B) and the bank behaviour are those of the real kernel but the halo columns of
 // the group's two ends are wrong.  It answers "what is a fourth wave per SIMD worth" before the exact 40 960-byte layout is built.
-template <int OCC, int LAYOUT>
-__global__ __launch_bounds__(256, OCC) void k_cube125_q(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
+template <int NW, int OCC, int LAYOUT>
+__global__ __launch_bounds__(64 * NW, OCC) void k_cube125_q(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
                                                         size_t step, const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, Coeffs cf) {
-  constexpr int R = 2, NW = 4;
+  constexpr int R = 2;
   using TL = DenseTile<kCube125>;
   using X = DX<kCube125>;
   constexpr int E = TL::ELEMS;
@@ -383,10 +383,10 @@ __global__ __launch_bounds__(256, OCC) void k_cube125_q(const uint32_t *__restri
     HIP_TRY(hipGetLastError());
     return BRK_OK;
   }
-  if (stencil_id == BRK_MPI125 && (variant == 16 || variant == 17)) { // round-5 experiment: the lean 125-point kernel at 4 / 3 waves per SIMD (timing diagnostic, wrong i-ends)
-    brk_note_kernel(variant == 16 ? "k_cube125_q<4,0>" : "k_cube125_q<3,0>");
-    if (variant == 16) hipLaunchKernelGGL((k_cube125_q<4, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
-    else hipLaunchKernelGGL((k_cube125_q<3, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+  if (stencil_id == BRK_MPI125 && (variant == 16 || variant == 17)) { // round-5 experiment: the lean 125-point kernel at 4 waves per SIMD in groups of 4 (16) / 8 (17) waves (timing diagnostic, wrong i-ends)
+    brk_note_kernel(variant == 16 ? "k_cube125_q<4,4,0>" : "k_cube125_q<8,4,0>");
+    if (variant == 16) hipLaunchKernelGGL((k_cube125_q<4, 4, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
+    else hipLaunchKernelGGL((k_cube125_q<8, 4, 0>), dim3((((n + 7) / 8 + 7) / 8) * 8), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf); // 17: 8-wave groups, 2 per CU
     HIP_TRY(hipGetLastError());
     return BRK_OK;
   }

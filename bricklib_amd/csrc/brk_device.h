@@ -67,6 +67,11 @@ struct CubeRegular {
 };
 int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                       uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st, const uint32_t *linkmask, const CubeRegular &cubereg = CubeRegular());
+// the 125-point kernel at four waves per SIMD for lists whose groups of four are fully linked i-neighbours of regular bricks
+// (brk_cube125q.hip; the box entry point proves that with all_regular over the cube-regular mask of a registered table)
+int launch_cube125_q(const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids, uint32_t n, const Coeffs &cf, hipStream_t st,
+                     uint32_t s1, uint32_t s2, bool predicted);
+int all_regular(const uint32_t *ids, uint32_t n, const uint32_t *mask, hipStream_t st, bool *out);
 int launch_cube_wg(int stencil_id, int nw, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
                    uint32_t first, uint32_t n, const Coeffs &cf, hipStream_t st);
 

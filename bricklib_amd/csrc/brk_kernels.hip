@@ -12,6 +12,7 @@
 //     faces) then meet in the same 4 MiB L2.
 // HBM-bound by design: 16 B of compulsory traffic per lattice update, no MFMA (not a contraction).
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -235,7 +236,7 @@ int link_mask_locked(const uint32_t *adj, const uint32_t **out);
 // ... and the six face neighbours of every brick as one aligned 32-byte row (see k_face_table)
 int face_table_locked(const uint32_t *adj, const uint32_t **out);
 // ... and, per pair of id strides, one bit per brick "the neighbours are the ids a lexicographic numbering with these strides predicts"
-int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, int cube, hipStream_t st, const uint32_t **out);
+int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, int cube, hipStream_t st, const uint32_t **out, uint64_t *uid = nullptr);
 
 // box_strides: the launch comes from the box entry point -- ids are base + (k * tot[1] + j) * tot[0] + i, strides {tot[0], tot[0] * tot[1]}
 int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids,
@@ -310,6 +311,19 @@ int launch_stencil(int id, const uint32_t *adj, const double *in, double *out, s
 #endif
 }
 
+// BRK_CUBE125_Q=0 in the environment (read once): the box entry point keeps k_cube_dense for the 125-point stencil also where the
+// four-waves-per-SIMD kernel applies -- for A/B measurements (bench.py, tools/kbench); development builds: variant 18 does the same
+bool cube125_q_enabled() {
+  static const bool on = [] {
+    const char *v = std::getenv("BRK_CUBE125_Q");
+    return !(v && v[0] == '0');
+  }();
+#ifdef BRK_DEV_KNOBS
+  if (g_variant[BRK_MPI125].load(std::memory_order_relaxed) != 0) return false; // any named variant (18 = "the default kernel, please") keeps k_cube_dense
+#endif
+  return on;
+}
+
 int make_geom(const long dimlist[3], const long padding[3], const long ghost[3], IterGeom &g, long &nb) {
   if (!dimlist || !padding || !ghost) return brk_fail(BRK_EINVAL, "null geometry");
   long a = 1, b = 1, sA[3], sB[3];
@@ -368,6 +382,10 @@ struct BoxList {
   uint64_t stamp;
   int device;
   hipEvent_t last_use; // recorded behind the most recent launch that reads `dev`
+  // 125-point kernel at four waves per SIMD (brk_cube125q.hip): is every brick of this list regular in the registered table whose
+  // cube-regular mask has the unique id q_uid?  (one reduction per list and mask; 0 = not examined yet)
+  uint64_t q_uid;
+  bool q_ok;
 };
 constexpr int kBoxCache = 16;
 BoxList g_box[kBoxCache];
@@ -470,6 +488,7 @@ int box_list_locked(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], 
     HIP_TRY(r);
   }
   std::memcpy(e.key, key, sizeof key);
+  e.q_uid = 0, e.q_ok = false;
   e.n = (uint32_t)host.size();
   e.device = device;
   e.stamp = ++g_box_clock;
@@ -553,6 +572,7 @@ struct AdjEntry {
     int cube; // 0: the six face neighbours are the predicted ones (7-point box kernel); 1: all 26 (cube kernels)
     uint32_t *dev;
     uint64_t stamp;
+    uint64_t uid; // never reused: what a cached verdict about this mask is keyed by (device pointers are recycled)
   };
   std::vector<Mask> masks;      // (s1, s2) -> device bit mask, at most kMaxMasks of them (least recently used one replaced)
   uint32_t *linkmask = nullptr; // k_link_mask, built by brk_adjacency_register
@@ -586,7 +606,7 @@ int same_device(const AdjEntry &e) {
 // the face-regularity mask of a registered table for id strides (s1, s2), built on first use of that pair (that one call is
 // synchronous on `st`: the strides are a property of the launch, not of the table); nullptr (and BRK_OK) when the table is not
 // registered.  Caller holds g_adj_mutex.
-int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, int cube, hipStream_t st, const uint32_t **out) {
+int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, int cube, hipStream_t st, const uint32_t **out, uint64_t *uid) {
   *out = nullptr;
   AdjEntry *e = find_locked(adj);
   if (!e) return BRK_OK;
@@ -594,6 +614,7 @@ int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, int cube,
     if (m.s1 == s1 && m.s2 == s2 && m.cube == cube) {
       m.stamp = ++g_mask_clock;
       *out = m.dev;
+      if (uid) *uid = m.uid;
       return BRK_OK;
     }
   if (int rc = same_device(*e)) return rc;
@@ -614,8 +635,10 @@ int regular_mask_locked(const uint32_t *adj, uint32_t s1, uint32_t s2, int cube,
     (void)hipFree(e->masks[victim].dev);
     e->masks.erase(e->masks.begin() + victim);
   }
-  e->masks.push_back({s1, s2, cube, mask, ++g_mask_clock});
+  const uint64_t stamp = ++g_mask_clock;
+  e->masks.push_back({s1, s2, cube, mask, stamp, stamp});
   *out = mask;
+  if (uid) *uid = stamp;
   return BRK_OK;
 }
 
@@ -833,6 +856,28 @@ extern "C" int brk_stencil_apply_box_ex(int id, const uint32_t *adj, const doubl
   const bool kpair = id == BRK_MPI25 || id == BRK_MPI13; // the stars march two k-consecutive bricks per wave over k-paired lists (k_star_km, brk_starwg.hip)
   if (int rc = box_list_locked(base, tot, lo, cnt, 8u, kpair, id == BRK_MPI25 ? 32u : 0u, &e)) return rc; // radius 4: i-chunks of 32 bricks (see box_list_locked)
   const uint32_t strides[2] = {tot[0], tot[0] * tot[1]};
+  if (id == BRK_MPI125 && cnt[0] % 8 == 0 && cube125_q_enabled()) {
+    // The 125-point kernel at four waves per SIMD (brk_cube125q.hip) handles groups of four fully linked i-neighbours only.  Over a
+    // REGISTERED table that is a provable property of a box: rows are multiples of 8 bricks (every group of four list entries is four
+    // consecutive bricks of one row, or four padding entries) and every brick of the box is regular (bit set in the cube-regular
+    // mask: all 26 neighbours are the predicted ids).  The second condition is reduced once per list and mask and remembered.
+    std::lock_guard<std::mutex> adj_lock(g_adj_mutex); // until the launch is enqueued (lifetime rule of the derived tables)
+    const uint32_t *cmask = nullptr;
+    uint64_t uid = 0;
+    if (int rc = regular_mask_locked(adj, strides[0], strides[1], 1, static_cast<hipStream_t>(s), &cmask, &uid)) return rc;
+    if (cmask) {
+      if (e->q_uid != uid) {
+        bool ok = false;
+        if (int rc = all_regular(e->dev, e->n, cmask, static_cast<hipStream_t>(s), &ok)) return rc;
+        e->q_uid = uid, e->q_ok = ok;
+      }
+      if (e->q_ok) {
+        if (int rc = launch_cube125_q(adj, in, out, step, e->dev, e->n, cf, static_cast<hipStream_t>(s), strides[0], strides[1], true)) return rc;
+        HIP_TRY(hipEventRecord(e->last_use, static_cast<hipStream_t>(s)));
+        return BRK_OK;
+      }
+    }
+  }
   if (int rc = launch_stencil(id, adj, in, out, step, e->dev, 0, e->n, coeff_host, s, kpair, reverse, strides)) return rc;
   HIP_TRY(hipEventRecord(e->last_use, static_cast<hipStream_t>(s)));
   return BRK_OK;

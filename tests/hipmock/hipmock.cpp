@@ -280,6 +280,62 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     run_stencil(ta.at(0) == brklib::kStarMpi13 ? BRK_MPI13 : BRK_MPI25, adj, in, out, step, list, cf);
     return;
   }
+  if (name.find("k_all_regular") != std::string::npos) { // (ids, n, mask, flag): *flag &= every listed brick has its bit set
+    const uint32_t *ids = arg<const uint32_t *>(args, 0);
+    const uint32_t n = arg<uint32_t>(args, 1);
+    const uint32_t *mask = arg<const uint32_t *>(args, 2);
+    uint32_t *flag = arg<uint32_t *>(args, 3);
+    need("brick id list", ids, (size_t)n * 4);
+    need("flag", flag, 4);
+    for (uint32_t q = 0; q < n; ++q) {
+      if (ids[q] == BRK_LIST_SKIP) continue;
+      need("cube regularity mask", mask + (ids[q] >> 5), 4);
+      if (!((mask[ids[q] >> 5] >> (ids[q] & 31)) & 1u)) *flag = 0u;
+    }
+    return;
+  }
+  if (name.find("k_cube125_q<") != std::string::npos) { // (adj, in, out, step, ids, n, cf, cs1, cs2)
+    const uint32_t *adj = arg<const uint32_t *>(args, 0);
+    const double *in = arg<const double *>(args, 1);
+    double *out = arg<double *>(args, 2);
+    const size_t step = arg<size_t>(args, 3);
+    const uint32_t *ids = arg<const uint32_t *>(args, 4);
+    const uint32_t n = arg<uint32_t>(args, 5);
+    const brklib::Coeffs cf = arg<brklib::Coeffs>(args, 6);
+    const uint32_t cs1 = arg<uint32_t>(args, 7), cs2 = arg<uint32_t>(args, 8);
+    need("brick id list", ids, (size_t)n * 4);
+    // what the launcher must have proven: padding in whole groups of four, the four entries of a group are consecutive i-neighbours,
+    // every brick's row is the predicted one (the kernel computes it and loads no fallback halo)
+    for (uint32_t g = 0; g + 3 < n || g < n; g += 4) {
+      int skips = 0;
+      for (uint32_t q = g; q < g + 4 && q < n; ++q) skips += ids[q] == BRK_LIST_SKIP;
+      if (skips != 0 && skips != (int)std::min<uint32_t>(4, n - g)) {
+        fprintf(stderr, "hipmock: k_cube125_q over a group that is partly padding (entries %u..)\n", g);
+        abort();
+      }
+      if (skips) continue;
+      if (g + 4 > n) {
+        fprintf(stderr, "hipmock: k_cube125_q over an incomplete last group\n");
+        abort();
+      }
+      for (uint32_t q = g; q < g + 4; ++q) {
+        const uint32_t b = ids[q];
+        need("adjacency row", adj + (size_t)b * 27, 108);
+        for (int e = 0; e < 27; ++e)
+          if (adj[(size_t)b * 27 + e] != b + (uint32_t)(e / 9 - 1) * cs2 + (uint32_t)((e / 3) % 3 - 1) * cs1 + (uint32_t)(e % 3 - 1)) {
+            fprintf(stderr, "hipmock: k_cube125_q over brick %u whose entry %d is not the predicted one\n", b, e);
+            abort();
+          }
+        if (q > g && ids[q] != ids[q - 1] + 1) {
+          fprintf(stderr, "hipmock: k_cube125_q over a group whose entries are not consecutive i-neighbours\n");
+          abort();
+        }
+      }
+    }
+    const std::vector<uint32_t> list = checked_list(adj, in, out, step, ids, 0, n);
+    run_stencil(BRK_MPI125, adj, in, out, step, list, cf);
+    return;
+  }
   if (name.find("k_face_table") != std::string::npos) {
     const uint32_t *adj = arg<const uint32_t *>(args, 0);
     const uint32_t nb = arg<uint32_t>(args, 1);

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -160,6 +161,28 @@ static int launches() {
     if (pass == 1) {
       REQ(brk_adjacency_release(adj_dev) == BRK_OK);
       REQ(brk_adjacency_release(adj_dev) != BRK_OK);
+    }
+  }
+  // the 125-point kernel at four waves per SIMD: box entry point, registered table, rows of 8 bricks, every brick regular -- and the
+  // same box over a table with ONE irregular brick (the reduction over the mask must send it back to the general kernel)
+  {
+    const long d2[3] = {10, 4, 5};
+    const uint32_t t2[3] = {10, 4, 5}, lo2[3] = {1, 1, 1}, c2[3] = {8, 2, 3};
+    const size_t nb2 = 10 * 4 * 5;
+    std::vector<uint32_t> g2(nb2), a2(nb2 * 27);
+    REQ(brk_init_grid(d2, g2.data(), a2.data()) == BRK_OK);
+    for (int twist = 0; twist < 2; ++twist) {
+      if (twist) a2[(size_t)((2 * 4 + 1) * 10 + 4) * 27 + 26] = 0; // one corner neighbour of an interior brick points at the dummy brick
+      uint32_t *adj2 = dev_u32(a2.data(), a2.size());
+      double *i2 = dev_doubles(nb2 * 512, 0.0), *o2 = dev_doubles(nb2 * 512, 0.0);
+      for (size_t q = 0; q < nb2 * 512; ++q) i2[q] = std::cos(0.002 * (double)q);
+      REQ(brk_adjacency_register(adj2, (uint32_t)nb2) == BRK_OK);
+      for (uint32_t flags : {0u, (uint32_t)BRK_SWEEP_REVERSE, 0u})
+        REQ(brk_stencil_apply_box_ex(BRK_MPI125, adj2, i2, o2, 512, 0, t2, lo2, c2, nullptr, flags, nullptr) == BRK_OK);
+      const std::string kn = brk_last_kernel();
+      REQ(twist ? kn.find("k_cube_dense") == 0 : kn.find("k_cube125_q") == 0);
+      REQ(brk_adjacency_release(adj2) == BRK_OK);
+      REQ(hipFree(adj2) == hipSuccess && hipFree(i2) == hipSuccess && hipFree(o2) == hipSuccess);
     }
   }
   // stencil given as taps

@@ -1396,6 +1396,59 @@ def test_registered_adjacency_box_form_is_bit_identical(oracle, dev):
     assert lib.brk_adjacency_release(C.c_void_p(t.data_ptr())) != 0
 
 
+@pytest.mark.parametrize("shape", [(10, 5, 6), (18, 12, 7), (34, 4, 11), (66, 19, 5)])
+def test_125pt_four_waves_per_simd_kernel(oracle, dev, shape):
+    """k_cube125_q (brk_cube125q.hip, round 5): the 125-point stencil through the box entry point over a REGISTERED table whose box is
+    fully regular and has rows of a multiple of 8 bricks runs the four-waves-per-SIMD kernel (exact 40 960-byte group layout, corner
+    cells in registers, shift slots aliased into the tiles) -- the oracle's result (stencils/fake.h:87-341), both sweep directions, with
+    neighbour bricks that differ in every halo region (random field incl. the ghost ring).  The same box over an unregistered table,
+    over a table with one irregular brick, and a box whose rows are not a multiple of 8 bricks keep k_cube_dense; all agree to rounding."""
+    ni, nj, nk = shape
+    grid, info0 = bl.init_grid(shape, None)
+    adj = info0.adj_host.copy()
+    nbricks = adj.shape[0]
+    rng = np.random.default_rng(21)
+    st = bl.BrickStorage.allocate(nbricks, 512, dev)
+    st.dat.copy_(torch.from_numpy(rng.random(nbricks * 512)))
+    hin = st.dat.cpu().numpy()
+    g3 = grid.reshape(nk, nj, ni)
+    ids = np.ascontiguousarray(g3[1:-1, 1:-1, 1:-1]).reshape(-1)
+    want = np.zeros_like(hin)
+    oracle.brick_stencil(ST_MPI125, adj, hin, want, 512, ids=ids)
+    box = (0, shape, (1, 1, 1), (ni - 2, nj - 2, nk - 2))
+    reg = bl.BrickInfo(adj, dev)                                             # registers its device table
+    for reverse in (False, True, False):
+        out = bl.BrickStorage.allocate(nbricks, 512, dev)
+        bl.apply_stencil("mpi125pt", bl.Brick(reg, st, 0), bl.Brick(reg, out, 0), box=box, reverse=reverse)
+        assert bl.last_kernel().startswith("k_cube125_q"), bl.last_kernel()
+        got = out.dat.cpu().numpy()
+        assert np.abs(got - want).max() <= TOL, (shape, reverse, np.abs(got - want).max())
+    # fallbacks: unregistered table; one irregular brick (a corner entry of an interior brick points at the dummy brick); ragged rows
+    raw = bl.BrickInfo(grid_to_device(adj.reshape(-1), dev).reshape(-1, 27))
+    out = bl.BrickStorage.allocate(nbricks, 512, dev)
+    bl.apply_stencil("mpi125pt", bl.Brick(raw, st, 0), bl.Brick(raw, out, 0), box=box)
+    assert bl.last_kernel().startswith("k_cube_dense"), bl.last_kernel()
+    assert np.abs(out.dat.cpu().numpy() - want).max() <= TOL
+    adj2 = adj.copy()
+    adj2[g3[nk // 2, nj // 2, ni // 2], 26] = 0
+    want2 = np.zeros_like(hin)
+    oracle.brick_stencil(ST_MPI125, adj2, hin, want2, 512, ids=ids)
+    twisted = bl.BrickInfo(adj2, dev)
+    out = bl.BrickStorage.allocate(nbricks, 512, dev)
+    bl.apply_stencil("mpi125pt", bl.Brick(twisted, st, 0), bl.Brick(twisted, out, 0), box=box)
+    assert bl.last_kernel().startswith("k_cube_dense"), bl.last_kernel()
+    assert np.abs(out.dat.cpu().numpy() - want2).max() <= TOL
+    if ni - 2 > 8:
+        box7 = (0, shape, (2, 1, 1), (ni - 3, nj - 2, nk - 2))                # rows of ni - 3 bricks: not a multiple of 8
+        ids7 = np.ascontiguousarray(g3[1:-1, 1:-1, 2:-1]).reshape(-1)
+        want7 = np.zeros_like(hin)
+        oracle.brick_stencil(ST_MPI125, adj, hin, want7, 512, ids=ids7)
+        out = bl.BrickStorage.allocate(nbricks, 512, dev)
+        bl.apply_stencil("mpi125pt", bl.Brick(reg, st, 0), bl.Brick(reg, out, 0), box=box7)
+        assert bl.last_kernel().startswith("k_cube_dense"), bl.last_kernel()
+        assert np.abs(out.dat.cpu().numpy() - want7).max() <= TOL
+
+
 @pytest.mark.parametrize("shape", [(10, 10, 10), (7, 21, 5), (14, 6, 9), (66, 11, 4)])
 def test_star_two_bricks_per_wave_kpaired_lists(oracle, dev, shape):
     """k_star_kp (two bricks per wave; the planes between the two bricks of a k-pair are loaded once): the 25-point star over

@@ -256,7 +256,7 @@ rows25)  # star kernels (march, k-paired lists declared) over placed storages: r
 dmacube) # VARIANTS=1 build: cube kernels staged by LDS-DMA (variant 15, k_cube_dma) vs through registers (0), registered table, placed storages, box and list form
   for sid in 1 5 7; do run -n 512 -s $sid -S -Q -b -v 115,100 -i 40 -r2 4; run -n 512 -s $sid -S -Q -o 8 -v 115,100 -i 40 -r2 3; done ;;
 q125)    # VARIANTS=1 build, round 5: the lean 125-point kernel at 4 waves per SIMD (variant 16: timing diagnostic, wrong i-ends) vs the default (0), registered table, placed storages
-  run -n 512 -s 5 -S -Q -b -v 116,100 -i 40 -r2 4; run -n 512 -s 5 -S -Q -o 8 -v 116,100 -i 40 -r2 3 ;;
+  run -n 512 -s 5 -S -Q -b -v 116,117,100 -i 40 -r2 4; run -n 512 -s 5 -S -Q -o 8 -v 116,117,100 -i 40 -r2 3 ;;
 dpp7)    # VARIANTS=1 build, round 5: 7-point kernel with the +-i neighbours by DPP (variant 13) vs the default (0), list form, placed storages
   for sid in 0 2; do run -n 512 -s $sid -S -Q -o 8 -v 113,100 -i 100 -r2 4; done ;;
 ichunk)  # round 5: rows of a block cut along i into chunks (kbench -C): the k-reuse distance of the k-paired star lists halves without fewer rows per block.  Default build.
