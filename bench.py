@@ -108,6 +108,7 @@ def parse():
     ap.add_argument("--one-way", action="store_true", help="accepted for compatibility: one direction is the default")
     ap.add_argument("--weak-zigzag", action="store_true", help="weak workload: alternate the direction of successive sweeps too (no gain measured: "
                                                                 "a ping-pong sweep reads what the previous one wrote with non-temporal stores)")
+    ap.add_argument("--no-weak-prediction", action="store_true", help="single workload: skip the emulated-exchange rows (predicted_weak_efficiency) behind weak_workload_on_this_gpu")
     ap.add_argument("--no-config3", action="store_true", help="single workload: skip the 27-/125-/13-/25-point lines on the same grid")
     return ap.parse_args()
 
@@ -719,7 +720,9 @@ def run_weak(args, bl, dev, rank, world):
                  for t in range(1, S + 1)]                       # part of sweep t that can run before the ghosts land
         # while it overlaps with sweeps the exchange is taken to progress 1.2x slower (shared HBM): a window of h ms of
         # independent compute retires h / 1.2 ms of exchange
-        cost = {("plain", 0): T + probe_ms, ("surface", 0): 1.03 * T + max(0.0, probe_ms - 0.2 * T / 1.2)}
+        # constants re-fitted in round 5 to the fused cycle at HEAD (profiles/r05_e_emulated_exchange_schedules.txt: cycle 1.84 ms; surface
+        # costs +4.5 % and hides 0.35 T = 0.65 ms, deep costs +6 % at full depth and hides sum(share) x pass / 1.2 = 1.1 ms)
+        cost = {("plain", 0): T + probe_ms, ("surface", 0): 1.045 * T + max(0.0, probe_ms - 0.35 * T)}
         for k in range(2, S + 1):                               # deep with k split passes: +6 % at full depth (measured)
             cost[("deep", k)] = (1.0 + 0.06 * k / S) * T + max(0.0, probe_ms - sum(share[:k]) * sweep_ms / 1.2)
         schedule, deep_depth = min(cost, key=cost.get)
@@ -1017,6 +1020,27 @@ def main():
                                                       "updates_per_pass": w["updates_per_pass"], "schedule": w["schedule"],
                                                       "conservation_rel_drift": w["conservation_rel_drift"],
                                                       "exchange_self_check": w["exchange_self_check"]}
+                if not args.no_weak_prediction:
+                    # What the first multi-GPU run will be compared with: the same cycle with its exchange STRETCHED by a calibrated spin
+                    # kernel on the exchange stream (one GPU cannot run an inter-GPU exchange), `--schedule auto` choosing as it will
+                    # there.  predicted efficiency = cycle of this GPU alone (above) / stretched cycle: what a rank of an N-GPU weak run
+                    # sustains if its exchange takes that long.  Which row applies is a property of the fabric: a 2x2x2 periodic rank
+                    # sends 67 MB to each of its three face peers, 0.67 / 0.9 / 1.34 ms at 100 / 75 / 50 GB/s per link and direction.
+                    rows = {}
+                    for x_ms in (0.5, 1.0, 1.5, 2.0):
+                        a3 = copy.copy(a2)
+                        a3.schedule, a3.emulate_exchange_ms, a3.steps, a3.warmup = "auto", x_ms, 20, 3
+                        torch.cuda.empty_cache()
+                        w3, _ = run_weak(a3, bl, dev, 0, 1)
+                        ms3 = w3["wall"] / w3["K"] * 1e3
+                        rows["%.1f" % x_ms] = {"cycle_ms": ms3, "schedule": w3["schedule"], "deep_depth": w3.get("deep_depth"),
+                                               "predicted_efficiency": (w["wall"] / w["K"] * 1e3) / ms3}
+                    extra["predicted_weak_efficiency"] = {
+                        "by_emulated_exchange_ms": rows, "base_cycle_ms": w["wall"] / w["K"] * 1e3,
+                        "what": "weak cycle of this one GPU (exchange + 8 sweeps as 4 fused passes, 512^3 + ghost per rank) with the exchange stretched by a spin "
+                                "kernel on its stream, --schedule auto; efficiency = unstretched plain cycle / stretched cycle.  Not a scaling curve (none can be "
+                                "measured on one GPU): the number the first 8-GPU run is to be compared with.  Face-peer message of a 2x2x2 periodic rank: 67 MB "
+                                "= 0.67 / 0.9 / 1.34 ms at 100 / 75 / 50 GB/s per link and direction"}
             except Exception as e:
                 extra["weak_workload_on_this_gpu"] = {"error": repr(e)}
     elif workload == "strong":

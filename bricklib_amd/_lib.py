@@ -21,6 +21,11 @@ class Region(C.Structure):
                 ("len", C.c_uint32), ("first_pad", C.c_uint32), ("last_pad", C.c_uint32)]
 
 
+class PlacePartner(C.Structure):
+    """brk_place_partner: a live placed storage and the wanted relation (0 = BRK_PLACE_OPPOSITE, 1 = BRK_PLACE_SAME)"""
+    _fields_ = [("storage_dev", C.c_void_p), ("relation", C.c_int)]
+
+
 class Placement(C.Structure):
     """brk_placement: what brk_storage_alloc measured while it placed a storage"""
     _fields_ = [("candidates", C.c_int), ("chosen", C.c_int), ("probe_bricks", C.c_int), ("spacer_gib", C.c_int), ("ms_chosen", C.c_double), ("ms_worst", C.c_double), ("ms_same_allocation", C.c_double)]
@@ -57,6 +62,7 @@ def _load():
         L.brk_set_variant.argtypes = [C.c_int, C.c_int]
     L.brk_link_copy.argtypes = [vp, C.c_uint32, C.c_uint64, vp]
     L.brk_storage_alloc.argtypes = [C.c_size_t, C.POINTER(vp), C.POINTER(Placement)]
+    L.brk_storage_alloc_ex.argtypes = [C.c_size_t, C.POINTER(PlacePartner), C.c_uint32, vp, C.POINTER(vp), C.POINTER(Placement)]
     L.brk_storage_free.argtypes = [vp]
     L.brk_placement_probe.argtypes = [vp, vp, C.c_size_t, vp, f64p]
     L.brk_array_to_brick.argtypes = [L3, L3, L3, vp, vp, vp, C.c_size_t, vp]
@@ -163,7 +169,7 @@ ABI_SYMBOLS = [
     "brk_exchange_begin", "brk_exchange_transport", "brk_exchange_end", "brk_exchange_run", "brk_exchange_loopback",
     "brk_exchange_view_buffer", "brk_exchange", "brk_comm_unique_id", "brk_comm_init_rank", "brk_comm_destroy", "brk_comm_rank", "brk_comm_library",
     "brk_adjacency_register", "brk_adjacency_release", "brk_decomp_build_order", "brk_skin3d_order",
-    "brk_storage_alloc", "brk_storage_free", "brk_placement_probe", "brk_finalize", "brk_last_kernel",
+    "brk_storage_alloc", "brk_storage_alloc_ex", "brk_storage_free", "brk_placement_probe", "brk_finalize", "brk_last_kernel",
 ]
 
 

@@ -8,7 +8,7 @@ import torch
 import os
 import sys
 
-from ._lib import Placement, check, l3, lib
+from ._lib import PlacePartner, Placement, check, l3, lib
 
 BRICK_TOLERANCE = 1e-6  # include/cmpconst.h:9
 BDIM = (8, 8, 8)
@@ -83,11 +83,20 @@ class _PlacedMemory:
     """Device memory from brk_storage_alloc, handed to torch through __cuda_array_interface__ (torch keeps this object alive for
     as long as a tensor aliases the memory) and given back with brk_storage_free when the last tensor is gone."""
 
-    def __init__(self, nelem, device):
+    def __init__(self, nelem, device, partners=None):
         self.device, self.nelem = device, int(nelem)
         ptr, rep = C.c_void_p(), Placement()
         with torch.cuda.device(device):
-            check(lib.brk_storage_alloc(self.nelem * 8, C.byref(ptr), C.byref(rep)))
+            if partners is None:
+                check(lib.brk_storage_alloc(self.nelem * 8, C.byref(ptr), C.byref(rep)))
+            else:   # [(placed BrickStorage, "opposite" | "same")]: brk_storage_alloc_ex, probes on torch's current stream
+                tab = (PlacePartner * max(1, len(partners)))()
+                for q, (st, rel) in enumerate(partners):
+                    if st.placement is None:
+                        raise ValueError("BrickStorage.allocate: a partner must be a placed storage (BrickStorage.allocate of at least PLACE_MIN_BYTES)")
+                    tab[q].storage_dev, tab[q].relation = st.dat.data_ptr(), {"opposite": 0, "same": 1}[rel]
+                check(lib.brk_storage_alloc_ex(self.nelem * 8, tab, len(partners), C.c_void_p(torch.cuda.current_stream(device).cuda_stream),
+                                               C.byref(ptr), C.byref(rep)))
         self.ptr = ptr.value
         self.report = {"candidates": rep.candidates, "chosen": rep.chosen, "probe_bricks": rep.probe_bricks, "spacer_gib": rep.spacer_gib,
                        "probe_sweep_ms_chosen": rep.ms_chosen, "probe_sweep_ms_worst": rep.ms_worst,
@@ -104,28 +113,34 @@ class _PlacedMemory:
                 pass
 
 
-PLACE_MIN_BYTES = 64 << 20     # brk_storage_alloc measures storages from this size on (include/brk.h)
+def place_min_bytes():
+    """brk_storage_alloc measures storages from this size on: 512 MiB -- a probe over less runs out of the 256-MiB Infinity Cache
+    (include/brk.h; BRK_PLACEMENT_MIN_BYTES overrides it, as in the library: tests of the machinery on small storages)"""
+    v = os.environ.get("BRK_PLACEMENT_MIN_BYTES")
+    return int(v) if v and int(v) > 0 else 512 << 20
 
 
 class BrickStorage:
     """Flat storage of `chunks` chunks of `step` elements (include/brick.h:53-82).
 
-    Device storages of 64 MiB and more are PLACED (brk_storage_alloc, include/brk.h): HBM consists of regions of about 8 GiB, and
-    a sweep between two storages in regions of the same kind runs 2.7 % slower than between regions of different kinds, so the
+    Device storages of 512 MiB and more are PLACED (brk_storage_alloc, include/brk.h): the device allocations of a process fall into
+    two kinds, and a sweep between two storages of the same kind runs 2.7 % slower than between storages of different kinds, so the
     allocation is a measured one -- see bricklib_amd/csrc/brk_place.hip.  `placement` holds what was measured (None for small,
-    host or BRK_PLACEMENT=0 storages, which come from torch's allocator as before)."""
+    host or BRK_PLACEMENT=0 storages, which come from torch's allocator as before).  By default a storage is placed against the one
+    allocated before it as a read / write pair; `partners=[(storage, "opposite" | "same"), ...]` names the storages a sweep will pair
+    it with and how ("same": two fields a sweep reads together)."""
 
     def __init__(self, dat, chunks, step, placement=None):
         self.dat, self.chunks, self.step, self.placement = dat, int(chunks), int(step), placement
 
     @staticmethod
-    def allocate(chunks, step, device="cuda"):
+    def allocate(chunks, step, device="cuda", partners=None):
         n = int(chunks) * int(step)
         dev = torch.device(device)
-        if dev.type == "cuda" and n * 8 >= PLACE_MIN_BYTES and os.environ.get("BRK_PLACEMENT", "1") != "0":
+        if dev.type == "cuda" and n * 8 >= place_min_bytes() and os.environ.get("BRK_PLACEMENT", "1") != "0":
             if dev.index is None:
                 dev = torch.device("cuda", torch.cuda.current_device())
-            mem = _PlacedMemory(n, dev)
+            mem = _PlacedMemory(n, dev, partners)
             dat = torch.as_tensor(mem, device=dev)
             if dat.data_ptr() != mem.ptr or dat.dtype != torch.float64 or dat.numel() != n:
                 raise RuntimeError("BrickStorage.allocate: torch did not alias the placed storage")

@@ -15,6 +15,7 @@
 // rate of the device is measured first (a sweep between the two halves of ONE allocation) -- and moves on behind untouched spacer
 // allocations when every back-to-back candidate is of the partner's kind.  50-150 ms per storage, at setup.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -33,14 +34,13 @@ struct Placed {
 std::mutex g_place_mutex;
 std::vector<Placed> g_placed; // live storages handed out by brk_storage_alloc, in allocation order
 
-constexpr size_t kMinPlaced = (size_t)64 << 20;      // smaller storages are not worth a measurement
+constexpr size_t kMinPlaced = (size_t)512 << 20;     // smaller storages are not measured: the probe would run out of the 256-MiB Infinity Cache (min_placed_bytes)
 constexpr size_t kCandidateBudget = (size_t)28 << 30; // memory held by back-to-back candidates while one storage is placed
 constexpr int kMinCandidates = 6, kMaxCandidates = 24; // runs of up to 11 consecutive allocations of one kind are common
 // ... and runs of 25 x 1.2 GB and a 45-GiB allocation of one kind have been seen: when the back-to-back candidates show one rate only,
 // SPACERS (allocated, never touched, freed with the rejected candidates) move the next candidates further on
 constexpr size_t kSpacerGiB[] = {4, 8, 16, 16, 16};
 constexpr size_t kHeldBudget = (size_t)72 << 30; // everything held at once while one storage is placed, and never more than a third of what is free
-constexpr double kBothKindsSeen = 0.985;               // the two sweep rates are 2.5-3 % apart, repeats of one pair within 0.3 %
 constexpr uint32_t kMaxProbeEdge = 82;                 // bricks per axis of the probe grid: at most 82^3 x 4 KiB = 2.3 GB swept per launch
 
 // The measurement is the production sweep itself: the 7-point stencil (brk_stencil_apply_box, the kernel behind the headline) from
@@ -110,23 +110,59 @@ extern "C" int brk_placement_probe(const void *a_dev, void *b_dev, size_t bytes,
   return probe_locked(g, a_dev, b_dev, static_cast<hipStream_t>(s), ms_per_sweep);
 }
 
-extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *report) {
+// Minimum size of a storage (and of every partner) for a measurement: below it the probe sweep stays inside the 256-MiB Infinity Cache
+// and neither kind shows (the candidates would be picked by noise, behind up to 60 GiB of spacer allocations).  Input plus output of a
+// probe must clearly exceed the cache: 512 MiB per storage.  BRK_PLACEMENT_MIN_BYTES overrides it (tests of the machinery on small
+// storages; read at every call).
+static size_t min_placed_bytes() {
+  if (const char *v = std::getenv("BRK_PLACEMENT_MIN_BYTES")) {
+    const long long n = std::atoll(v);
+    if (n > 0) return (size_t)n;
+  }
+  return kMinPlaced;
+}
+
+extern "C" int brk_storage_alloc_ex(size_t bytes, const brk_place_partner *partners_in, uint32_t npartners, brk_stream s, void **out_dev,
+                                    brk_placement *report) {
   if (!out_dev) return brk_fail(BRK_EINVAL, "brk_storage_alloc: null result pointer");
   *out_dev = nullptr;
   if (report) std::memset(report, 0, sizeof *report);
   if (bytes == 0) return brk_fail(BRK_EINVAL, "brk_storage_alloc: zero bytes");
+  if (npartners && !partners_in) return brk_fail(BRK_EINVAL, "brk_storage_alloc_ex: %u partners but no table", npartners);
+  if (npartners > 8) return brk_fail(BRK_EINVAL, "brk_storage_alloc_ex: at most 8 partners");
+  hipStream_t st = static_cast<hipStream_t>(s);
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(g_place_mutex);
-  // the storage a sweep will pair this one with: the most recent live one of this device that is worth measuring.  ONE partner: there are
-  // two kinds, so a chain of storages placed each against its predecessor alternates A B A B -- what ping-pong pairs and the three
-  // rotating storages of the strong driver (0 -> 1 -> 2 -> 1 -> 0) need; against two partners of different kinds nothing can be gained
-  std::vector<Placed> partners;
-  for (size_t q = g_placed.size(); q-- > 0 && partners.size() < 1;)
-    if (g_placed[q].device == device && g_placed[q].bytes >= kMinPlaced) partners.push_back(g_placed[q]);
+  const size_t min_bytes = min_placed_bytes();
+  struct Partner {
+    Placed p;
+    int relation;
+  };
+  std::vector<Partner> partners;
+  if (npartners == 0) {
+    // default: the storage a sweep will pair this one with is the most recent live one of this device that is worth measuring, and
+    // the pair is a read / write pair (OPPOSITE kinds): a chain of storages placed each against its predecessor alternates A B A B --
+    // what ping-pong pairs and the three rotating storages of the strong driver (0 -> 1 -> 2 -> 1 -> 0) need
+    for (size_t q = g_placed.size(); q-- > 0 && partners.empty();)
+      if (g_placed[q].device == device && g_placed[q].bytes >= min_bytes) partners.push_back({g_placed[q], BRK_PLACE_OPPOSITE});
+  } else {
+    for (uint32_t q = 0; q < npartners; ++q) {
+      if (partners_in[q].relation != BRK_PLACE_OPPOSITE && partners_in[q].relation != BRK_PLACE_SAME)
+        return brk_fail(BRK_EINVAL, "brk_storage_alloc_ex: partner %u: relation %d (BRK_PLACE_OPPOSITE or BRK_PLACE_SAME)", q, partners_in[q].relation);
+      const Placed *found = nullptr;
+      for (const Placed &p : g_placed)
+        if (p.p == partners_in[q].storage_dev) found = &p;
+      if (!found) return brk_fail(BRK_EINVAL, "brk_storage_alloc_ex: partner %u (%p) did not come from brk_storage_alloc", q, partners_in[q].storage_dev);
+      if (found->device != device) return brk_fail(BRK_EINVAL, "brk_storage_alloc_ex: partner %u lives on device %d, the current device is %d", q, found->device, device);
+      partners.push_back({*found, partners_in[q].relation});
+    }
+  }
+  bool measurable = bytes >= min_bytes && !partners.empty();
+  for (const Partner &p : partners) measurable = measurable && p.p.bytes >= min_bytes;
   void *chosen = nullptr;
   const char *off = std::getenv("BRK_PLACEMENT"); // BRK_PLACEMENT=0: every storage is a plain hipMalloc (A/B runs)
-  if (bytes < kMinPlaced || partners.empty() || (off && off[0] == '0' && off[1] == 0)) {
+  if (!measurable || (off && off[0] == '0' && off[1] == 0)) {
     HIP_TRY(hipMalloc(&chosen, bytes));
   } else {
     size_t free_b = 0, total_b = 0;
@@ -134,17 +170,19 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
     int ncand = (int)std::min<size_t>(kMaxCandidates, std::max<size_t>(2, kCandidateBudget / bytes));
     ncand = (int)std::min<size_t>((size_t)ncand, std::max<size_t>(1, free_b / 2 / bytes));
     size_t probe_bytes = bytes; // one probe grid for all pairs: what the smallest storage involved can hold
-    for (const Placed &p : partners) probe_bytes = std::min(probe_bytes, p.bytes);
+    for (const Partner &p : partners) probe_bytes = std::min(probe_bytes, p.p.bytes);
     ProbeGrid grid;
     if (int rc0 = make_probe_grid(probe_bytes, grid)) return rc0;
     std::vector<void *> cands, spacers;
-    std::vector<double> score;
+    std::vector<double> score, first; // score: what is minimised; first: the sweep time against partner 0 (which kind is the candidate?)
+    std::vector<double> shown;        // the sweep time reported for a candidate: its slowest OPPOSITE partner (its fastest SAME one when there is none)
     int best = -1;
-    double worst = 0.0;
     int rc = BRK_OK;
     size_t held = 0;
     const size_t held_cap = std::min(kHeldBudget, free_b / 3);
-    // one more candidate: allocate, time the probe sweep from every partner into it; false when there is no room for it
+    // one more candidate: allocate, time the probe sweep from every partner into it; false when there is no room for it.
+    // OPPOSITE partners count with their sweep time, SAME partners against it: a read / write pair inside one kind is the SLOW one, so the
+    // candidate that sweeps slowest from a SAME partner is the one of that partner's kind.
     auto try_candidate = [&]() {
       void *c = nullptr;
       if (held + bytes > std::max(held_cap, bytes) || hipMalloc(&c, bytes) != hipSuccess) {
@@ -153,42 +191,54 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
       }
       cands.push_back(c);
       held += bytes;
-      double sc = 0.0; // milliseconds per probe sweep, slowest partner
-      for (const Placed &p : partners) {
+      double sc = 0.0, opp = 0.0, same = 1e30, ms0 = 0.0;
+      for (size_t q = 0; q < partners.size(); ++q) {
         double ms = 0.0;
-        rc = probe_locked(grid, p.p, c, nullptr, &ms);
+        rc = probe_locked(grid, partners[q].p.p, c, st, &ms);
         if (rc) return false;
-        sc = std::max(sc, ms);
+        if (q == 0) ms0 = ms;
+        if (partners[q].relation == BRK_PLACE_OPPOSITE) sc += ms, opp = std::max(opp, ms);
+        else sc -= ms, same = std::min(same, ms);
       }
       score.push_back(sc);
+      first.push_back(ms0);
+      shown.push_back(opp > 0.0 ? opp : same);
       if (best < 0 || sc < score[best]) best = (int)score.size() - 1;
-      worst = std::max(worst, sc);
       return true;
     };
     // What the SLOW rate is on this device, for this probe grid: the same sweep between the two halves of ONE allocation (an allocation is
-    // of one kind; should it straddle two, the reference reads fast and the search below merely runs longer).  With it a run of
-    // candidates that are all fast is recognised as such (no spacers), and so is a run that is all slow.
-    double slow_ref = 0.0;
+    // of one kind; should it straddle two, the reference reads fast and the search below merely runs longer).  Measured TWICE: the
+    // difference of the two is the repeatability of a probe on this device, and the gap that counts as "both kinds seen" follows from it
+    // (five times the repeatability, at least 1 %; the kinds lie 2.5-3 % apart, repeats within 0.3 %) instead of a constant.
+    double slow_ref = 0.0, noise = 0.003;
     const size_t half = (bytes + 4095) / 4096 * 4096; // the second half starts on a brick boundary whatever `bytes` is
     if (2 * half <= held_cap) {
       void *both = nullptr;
       if (hipMalloc(&both, 2 * half) == hipSuccess) {
-        rc = probe_locked(grid, both, static_cast<char *>(both) + half, nullptr, &slow_ref);
+        double r1 = 0.0, r2 = 0.0;
+        rc = probe_locked(grid, both, static_cast<char *>(both) + half, st, &r1);
+        if (rc == BRK_OK) rc = probe_locked(grid, both, static_cast<char *>(both) + half, st, &r2);
         (void)hipFree(both);
+        if (rc == BRK_OK && r1 > 0.0 && r2 > 0.0) slow_ref = std::max(r1, r2), noise = std::max(0.002, std::abs(r1 - r2) / slow_ref);
       } else {
         (void)hipGetLastError();
       }
     }
-    // both rates have been seen and a few candidates compared: done
+    const double gap = std::max(0.01, 5.0 * noise);
+    // both rates have been seen (against partner 0) and a few candidates compared: done
     auto contrast = [&]() {
-      return (int)score.size() >= std::min(kMinCandidates, ncand) && score[best] <= kBothKindsSeen * std::max(worst, slow_ref);
+      if ((int)first.size() < std::min(kMinCandidates, ncand)) return false;
+      const double hi = std::max(*std::max_element(first.begin(), first.end()), slow_ref), lo = *std::min_element(first.begin(), first.end());
+      return hi - lo >= gap * hi;
     };
     const bool force_spacers = std::getenv("BRK_PLACEMENT_TEST_SPACERS") != nullptr; // tests: take the spacer path whatever the candidates say
     for (int t = 0; t < ncand && rc == BRK_OK; ++t) {
       if (!try_candidate()) break;
       if (contrast() && !force_spacers) break;
     }
-    if (rc == BRK_OK && best >= 0 && (!contrast() || force_spacers)) {
+    // every back-to-back candidate is of one kind: move on behind untouched spacer allocations -- but only with a reference to tell the
+    // kinds apart by (without it "all alike" cannot be told from "all noise")
+    if (rc == BRK_OK && best >= 0 && ((slow_ref > 0.0 && !contrast()) || force_spacers)) {
       for (size_t gib : kSpacerGiB) {
         const size_t sp = gib << 30;
         void *spacer = nullptr;
@@ -217,14 +267,18 @@ extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *re
       for (size_t q = 0; q < spacers.size(); ++q) report->spacer_gib += (int)kSpacerGiB[q];
       report->chosen = best;
       report->probe_bricks = (int)((grid.edge - 2) * (grid.edge - 2) * (grid.edge - 2));
-      report->ms_chosen = score[best];
-      report->ms_worst = worst;
+      report->ms_chosen = shown[best];
+      report->ms_worst = *std::max_element(shown.begin(), shown.end());
       report->ms_same_allocation = slow_ref;
     }
   }
   g_placed.push_back({chosen, bytes, device});
   *out_dev = chosen;
   return BRK_OK;
+}
+
+extern "C" int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *report) {
+  return brk_storage_alloc_ex(bytes, nullptr, 0, nullptr, out_dev, report);
 }
 
 extern "C" int brk_storage_free(void *p_dev) {

@@ -63,7 +63,7 @@ const char *brk_last_error(void);
  * 1003: the ghost-zone exchange: brk_xplan_*, brk_exchange_*, brk_comm_*; 1004: brk_adjacency_register / _release;
  * 1005: brk_stencil_apply_{range,list,box}_ex with BRK_SWEEP_* flags; 1006: brk_comm_library, the development knob
  * brk_set_variant is no longer part of the ABI; 1007: brk_storage_alloc / brk_storage_free / brk_placement_probe;
- * 1008: brk_finalize, brk_last_kernel) */
+ * 1008: brk_finalize, brk_last_kernel; 1009: brk_storage_alloc_ex) */
 int brk_abi_version(void);
 /* Orderly end of the library's use of the GPU before a process leaves main(): waits for everything enqueued on the current device
  * and releases, on the CALLING thread, what the library itself holds there (box id lists and their events, derived tables of
@@ -178,18 +178,28 @@ typedef struct {
 } brk_link;
 int brk_link_copy(const brk_link *links_dev, uint32_t n, uint64_t max_bytes, brk_stream s);
 
-/* ---- placement of brick storages in HBM -----------------------------------------------------------------------------
- * The reference allocates device storage for a field wherever the allocator puts it (BrickStorage::allocate,
- * include/brick.h:68-75; movBrickStorage, include/brick-gpu.h:80-99: one cudaMalloc per storage).  On MI355X that leaves
- * 2.7 % of a bandwidth-bound sweep to chance: HBM is made of regions of about 8 GiB, and when a sweep's input and output
- * storages lie in regions of the same kind its read and write streams meet in the same DRAM banks (7-point, 512^3: 0.371 ms
- * against 0.361 ms; profiles/r04_g_*).  brk_storage_alloc is hipMalloc + a measurement: storages of at least 64 MiB are
- * placed where a 7-point sweep from the storage allocated before them into the new one runs fastest: 6 to 24
- * candidate allocations (at most 28 GiB of them) are measured -- when they all run at one rate, up to 60 GiB of untouched
- * spacer allocations move further candidates on (never more than a third of the free memory is held) --, all but the best
- * are freed before the call returns.
- * Synchronous, 50-150 ms per storage; meant for set-up.  Memory from brk_storage_alloc is released with brk_storage_free.
- * With BRK_PLACEMENT=0 in the environment every storage is a plain hipMalloc (for A/B runs).
+/* ---- WHERE a brick storage lies in HBM -------------------------------------------------------------------------------
+ * The reference allocates a storage wherever the allocator puts it (include/brick.h:68-75, include/brick-gpu.h:80-99).  On MI355X
+ * that leaves 2.7 % of a bandwidth-bound sweep to chance: the device allocations of a process fall into two kinds, and a sweep
+ * whose input and output storages are of the SAME kind runs slower (7-point, 512^3: 0.371 ms against 0.361 ms) than between
+ * storages of different kinds, while two READ streams prefer one kind (profiles/r04_g_*).  brk_storage_alloc[_ex] is hipMalloc +
+ * a measurement:
+ *   - partners: the live storages (from brk_storage_alloc) a sweep will pair the new one with, each with the wanted relation:
+ *     BRK_PLACE_OPPOSITE for a read / write pair (input and output of a sweep), BRK_PLACE_SAME for two fields a sweep READS
+ *     together.  brk_storage_alloc (no table) takes ONE partner, the most recent live storage of the device, as OPPOSITE: a chain
+ *     of allocations then alternates A B A B, what ping-pong pairs and three rotating storages need.  A three-field sweep
+ *     out = f(a, b): allocate a; b with {a, SAME}; out with {a, OPPOSITE}, {b, OPPOSITE}.
+ *   - 6 to 24 candidate allocations (at most 28 GiB of them) are made; the production 7-point sweep (brk_placement_probe) is timed
+ *     from every partner into every candidate on stream s; the candidate with the smallest (sum over OPPOSITE partners - sum over
+ *     SAME partners) of sweep times is kept, the others are freed before the call returns.  What counts as "both kinds seen" is
+ *     derived per call: the same sweep between the two halves of ONE allocation is the slow rate of the device, its repeat gives
+ *     the repeatability, the gap must be five times that (at least 1 %).  When all back-to-back candidates are of one kind, up
+ *     to 60 GiB of untouched spacer allocations move further candidates on (never more than a third of the free memory is held).
+ *   - COST: synchronous, 50-150 ms and tens of GiB of TRANSIENT allocations per storage; meant for set-up, not for a time loop.
+ *     Storages (or partners) below 512 MiB are plain hipMallocs (candidates = 0): a probe over less runs out of the 256-MiB
+ *     Infinity Cache and shows neither kind.  BRK_PLACEMENT=0 in the environment makes every storage a plain hipMalloc (A/B runs;
+ *     several ranks sharing one GPU should set it: the transient allocations of one rank can starve another).
+ * Memory from brk_storage_alloc[_ex] is released with brk_storage_free.
  * brk_placement_probe is the measurement itself: milliseconds per BRK_MPI7 sweep (brk_stencil_apply_box) from a into b over
  * the largest cubic brick grid (at most 82^3) that `bytes` hold, on stream s; b is OVERWRITTEN.                         */
 typedef struct {
@@ -197,11 +207,18 @@ typedef struct {
   int chosen;       /* index of the one kept */
   int probe_bricks; /* bricks swept per probe launch */
   int spacer_gib;   /* GiB of spacer allocations it took to reach candidates of the other kind (0: back-to-back candidates sufficed) */
-  double ms_chosen; /* probe sweep from the slowest partner into the chosen candidate */
-  double ms_worst;  /* ... into the slowest candidate seen */
+  double ms_chosen; /* probe sweep from the slowest OPPOSITE partner (without one: the fastest SAME partner) into the chosen candidate */
+  double ms_worst;  /* the same figure of the candidate where it is largest */
   double ms_same_allocation; /* the same sweep between the two halves of one allocation: the slow rate of this device (0: not measured) */
 } brk_placement;
+enum { BRK_PLACE_OPPOSITE = 0, BRK_PLACE_SAME = 1 };
+typedef struct {
+  const void *storage_dev; /* a live storage from brk_storage_alloc[_ex] on the current device */
+  int relation;            /* BRK_PLACE_OPPOSITE | BRK_PLACE_SAME */
+} brk_place_partner;
 int brk_storage_alloc(size_t bytes, void **out_dev, brk_placement *report /* may be NULL */);
+int brk_storage_alloc_ex(size_t bytes, const brk_place_partner *partners, uint32_t npartners, brk_stream s, void **out_dev,
+                         brk_placement *report /* may be NULL */);
 int brk_storage_free(void *p_dev);
 int brk_placement_probe(const void *a_dev, void *b_dev, size_t bytes, brk_stream s, double *ms_per_sweep);
 
