@@ -20,8 +20,11 @@
 //         read only by the halo pass of the end waves' edge lanes; those lanes load them straight into registers (two 16-byte loads) and
 //         select them in (four plane steps);
 //       - the shift slots are columns 2..5 of planes 2..5 of the wave's OWN tile: read by no other wave (neighbours read columns 0, 1 /
-//         6, 7), and dead for this wave once plane 5 has been requested, which is before output 0 is emitted.  The odd plane pitch (432
-//         = 16 mod 32 doubles) puts the two halves of a slot row into different banks: the aliased slots are conflict-free.
+//         6, 7), and dead for this wave once plane 5 has been requested, which is before output 0 is emitted.  Only 4 of a tile row's 8
+//         columns are private, so the 16-lane write groups and 32-lane read groups of a slot access meet two-way in the banks (PMC:
+//         SQ_LDS_BANK_CONFLICT 215 cycles per wave against 27 in k_cube_dense, LDS-array cycles +35 %): the price of 6 KiB of LDS.
+//         Moving the partial sums between lanes instead (DPP row_ror:8 + ds_swizzle xor 16 + ds_bpermute, 10 crossbar operations per
+//         output, no slot memory) was built and measured: the same time (0.5233-0.5334 vs 0.5275-0.5322 ms) -- profiles/EXPERIMENTS.md.
 // Arithmetic and summation order are those of cube125_accumulate_jout (stencils/fake.h:87-341 folded over its 10 coefficient classes).
 #include "brk_device.h"
 
@@ -45,8 +48,7 @@ struct QL { // one 4-wave group in LDS, offsets in doubles
   __host__ __device__ static constexpr int fcell(int side, int p, int row, int c) { return off(p) + F + frow(row) * 4 + side * 2 + c; }
 };
 static_assert(QL::off(12) == QL::TOTAL && QL::TOTAL * 8 == 40960, "the group fills a quarter of the CU's LDS exactly");
-static_assert(QL::off(3) - QL::off(2) == 432 && QL::off(5) - QL::off(4) == 432 && QL::off(4) % 32 == 0 && QL::off(2) % 32 == 0,
-              "shift slots: the two halves of a slot row lie 16 banks apart");
+static_assert(QL::off(3) - QL::off(2) == 432 && QL::off(5) - QL::off(4) == 432, "shift slots: planes 2..5 have the pitch of the mid planes");
 
 // Gather descriptors, one per lane and group: destination offset (doubles, pairs: even) | adjacency slot << 16 | source element << 21.
 //   group 0: the kj-edge pairs of the own tile (k-halo plane x j-halo row, 4 pairs of columns): 64, relative to the wave's tile
@@ -236,10 +238,10 @@ __global__ __launch_bounds__(256, 4) void k_cube125_q(const uint32_t *__restrict
         asm volatile("" : "+v"(b1), "+v"(b2)); // computed here, by all lanes, not sunk into the half-wave branch that uses it
         h1[k] = b1, h2[k] = b2;
       });
-  // shift slots: slot (row r, column c) = plane (4 | 2) + c / 4 of the own tile, row r, column 2 + c % 4
-  double *const s1 = tile + QL::off(4) + (lo >> 2) * 432 + 2 + (lo & 3), *const s2 = tile + QL::off(2) + (lo >> 2) * 432 + 2 + (lo & 3);
   double pb0 = 0.0, r[4] = {0.0, 0.0, 0.0, 0.0};
   auto retire = [&](int k) __attribute__((always_inline)) { store_result(&dst[k * 64 + lane], pb0 + ((r[0] + r[1]) + (r[2] + r[3]))); };
+  // shift slots: slot (row r, column c) = plane (4 | 2) + c / 4 of the own tile, row r, column 2 + c % 4
+  double *const s1 = tile + QL::off(4) + (lo >> 2) * 432 + 2 + (lo & 3), *const s2 = tile + QL::off(2) + (lo >> 2) * 432 + 2 + (lo & 3);
   q_stream<12, true>(
       cf, [&](int p, int d) __attribute__((always_inline)) { return lds[com[d] + QL::off(p)]; }, [&](int, double(&)[5]) __attribute__((always_inline)) {},
       [&](int k, double b0, double b1, double b2) __attribute__((always_inline)) {

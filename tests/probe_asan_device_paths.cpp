@@ -224,12 +224,31 @@ static int placement() {
   brk_placement rep;
   const size_t big = (size_t)65 << 20;
   const unsigned long live0 = hipmock_live_allocations();
+  // by default storages below 512 MiB are not measured (the probe would run out of the Infinity Cache): plain allocations
+  REQ(brk_storage_alloc(big, &a, &rep) == BRK_OK && a && rep.candidates == 0);
+  REQ(brk_storage_alloc(big, &b, &rep) == BRK_OK && b && rep.candidates == 0);
+  REQ(brk_storage_free(a) == BRK_OK && brk_storage_free(b) == BRK_OK);
+  a = b = nullptr;
+  setenv("BRK_PLACEMENT_MIN_BYTES", "67108864", 1); // the machinery on storages of 65 MiB
   REQ(brk_storage_alloc(4096, &small, &rep) == BRK_OK && small && rep.candidates == 0);
   REQ(brk_storage_alloc(big, &a, &rep) == BRK_OK && a && rep.candidates == 0); // nothing to place it against yet
   REQ(brk_storage_alloc(big + 4096, &b, &rep) == BRK_OK && b && rep.candidates >= 2 && rep.chosen >= 0 && rep.chosen < rep.candidates &&
       rep.ms_chosen > 0 && rep.ms_chosen <= rep.ms_worst && rep.probe_bricks == 23 * 23 * 23); // 65 MiB hold 25^3 bricks
   REQ(brk_storage_alloc(big - 4096 + 24, &c, nullptr) == BRK_OK && c); // a size that is no multiple of a brick, nor of 16 bytes
   REQ(hipmock_live_allocations() == live0 + 4); // the rejected candidates are gone
+  { // named partners (brk_storage_alloc_ex): a second READ field of a's kind, an output against both; refused: foreign pointers, relations
+    void *d = nullptr, *e = nullptr;
+    brk_place_partner same[1] = {{a, BRK_PLACE_SAME}}, both[2] = {{a, BRK_PLACE_OPPOSITE}, {b, BRK_PLACE_OPPOSITE}};
+    REQ(brk_storage_alloc_ex(big, same, 1, nullptr, &d, &rep) == BRK_OK && d && rep.candidates >= 2 && rep.ms_chosen > 0);
+    REQ(brk_storage_alloc_ex(big, both, 2, nullptr, &e, &rep) == BRK_OK && e && rep.candidates >= 2 && rep.ms_chosen <= rep.ms_worst);
+    brk_place_partner bad[1] = {{(char *)a + 4096, BRK_PLACE_OPPOSITE}}, rel[1] = {{a, 5}};
+    void *f = nullptr;
+    REQ(brk_storage_alloc_ex(big, bad, 1, nullptr, &f, nullptr) != BRK_OK && !f);
+    REQ(brk_storage_alloc_ex(big, rel, 1, nullptr, &f, nullptr) != BRK_OK && !f);
+    REQ(brk_storage_alloc_ex(big, nullptr, 3, nullptr, &f, nullptr) != BRK_OK);
+    REQ(brk_storage_free(d) == BRK_OK && brk_storage_free(e) == BRK_OK);
+    REQ(hipmock_live_allocations() == live0 + 4);
+  }
   double ms = 0.0;
   REQ(brk_placement_probe(a, b, big, nullptr, &ms) == BRK_OK && ms > 0.0);
   REQ(brk_placement_probe(a, (char *)b + 8, big, nullptr, &ms) != BRK_OK); // misaligned
@@ -239,6 +258,7 @@ static int placement() {
   REQ(brk_storage_free(a) == BRK_OK && brk_storage_free(c) == BRK_OK && brk_storage_free(small) == BRK_OK && brk_storage_free(nullptr) == BRK_OK);
   REQ(brk_storage_alloc(0, &a, nullptr) != BRK_OK && brk_storage_alloc(4096, nullptr, nullptr) != BRK_OK);
   REQ(hipmock_live_allocations() == live0);
+  unsetenv("BRK_PLACEMENT_MIN_BYTES");
   return 0;
 }
 
