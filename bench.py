@@ -108,6 +108,9 @@ def parse():
     ap.add_argument("--one-way", action="store_true", help="accepted for compatibility: one direction is the default")
     ap.add_argument("--weak-zigzag", action="store_true", help="weak workload: alternate the direction of successive sweeps too (no gain measured: "
                                                                 "a ping-pong sweep reads what the previous one wrote with non-temporal stores)")
+    ap.add_argument("--deep-early", choices=["auto", "0", "1"], default="auto",
+                    help="weak workload, deep schedule: the last sweep writes the surface first and the next exchange starts under the rest of that pass "
+                         "(+0.2 ms of exchange hidden for +2.5 %% of the cycle); auto = chosen with the schedule from the measured exchange time")
     ap.add_argument("--no-weak-prediction", action="store_true", help="single workload: skip the emulated-exchange rows (predicted_weak_efficiency) behind weak_workload_on_this_gpu")
     ap.add_argument("--no-config3", action="store_true", help="single workload: skip the 27-/125-/13-/25-point lines on the same grid")
     return ap.parse_args()
@@ -685,6 +688,7 @@ def run_weak(args, bl, dev, rank, world):
     xstream = torch.cuda.Stream()            # the exchange runs here when a schedule overlaps it with sweeps
     schedule = "plain" if args.no_overlap else args.schedule
     deep_depth = args.deep_depth
+    deep_early = args.deep_early == "1"      # "auto": priced below together with the schedule
     probe_ms = None
     if schedule == "auto":
         # measure, don't guess: the exchange alone (max over ranks) ...
@@ -725,7 +729,12 @@ def run_weak(args, bl, dev, rank, world):
         cost = {("plain", 0): T + probe_ms, ("surface", 0): 1.045 * T + max(0.0, probe_ms - 0.35 * T)}
         for k in range(2, S + 1):                               # deep with k split passes: +6 % at full depth (measured)
             cost[("deep", k)] = (1.0 + 0.06 * k / S) * T + max(0.0, probe_ms - sum(share[:k]) * sweep_ms / 1.2)
+        # deep with the early hand-over of the last sweep's surface (round 5, weak_cycle_deep(state=...)): the next exchange starts under
+        # the rest of the last late pass: +0.2 ms hidden for +2.5 % of the cycle (profiles/r05_e_*: pays from ~1.3 ms of exchange on)
+        cost[("deep+early", S)] = (1.0 + 0.06 + 0.025) * T + max(0.0, probe_ms - sum(share[:S]) * sweep_ms / 1.2 - 0.2)
         schedule, deep_depth = min(cost, key=cost.get)
+        if schedule == "deep+early":
+            schedule, deep_early = "deep", args.deep_early != "0"
     overlap = schedule != "plain"
     state = {}
     ic = 32 if name == "mpi25pt" else 0     # radius 4: rows of a block in i-chunks of 32 bricks (order.slabs: the k-halo planes stay in L2)
@@ -736,7 +745,8 @@ def run_weak(args, bl, dev, rank, world):
         deep_depth = S if not deep_depth else max(1, min(deep_depth, S))
 
         def step():
-            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=xstream, depth=deep_depth, full=whole, zigzag=args.weak_zigzag)
+            return weak_cycle_deep(sid, d, A, B, ex.exchange, lists, main=main, comm=xstream, depth=deep_depth, full=whole, zigzag=args.weak_zigzag,
+                                   state=state if deep_early else None)
     else:
         lists = SweepLists(d, dev, kpair=kp, icols=ic)
 
@@ -806,7 +816,7 @@ def run_weak(args, bl, dev, rank, world):
            "kernel_ms": e0.elapsed_time(e1) / K / S, "alg_bytes_per_launch": BYTES_PER_UPDATE * float(N) ** 3,   # per pass: one read + one write per cell
            "kernel": "%s passes over brick lists of BrickDecomp(%d^3): %d passes (%d sweeps) + 1 exchange per step; kernel_ms = step / %d" % (name, N, S, S * upd, S),
            "cart": cart, "overlap": overlap, "exchange": args.exchange, "transport": transport, "transport_fallback_reason": fallback_reason, "exchange_self_check": self_check,
-           "schedule": schedule, "deep_depth": deep_depth if schedule == "deep" else None, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
+           "schedule": schedule, "deep_depth": deep_depth if schedule == "deep" else None, "deep_early_handover": bool(deep_early) if schedule == "deep" else None, "schedule_probe_ms": probe_ms, "sweep_probe_ms": sweep_ms, "exchange_ms_alone": exchange_ms, "exchange_bytes_per_rank": sum(g["len"] for g in d.ghost) * 4096,
            "remote_bytes_per_rank": ex.bytes_remote, "messages_per_exchange": ex.messages, "phases": phases, "rccl_library": rccl_library(comm),
            "per_peer_send_bytes": {str(k): v for k, v in sorted(per_peer.items())},
            "per_peer_GBps_exchange_alone": {str(k): v / (exchange_ms * 1e-3) / 1e9 for k, v in sorted(per_peer.items())} if exchange_ms > 0 else None}
@@ -1033,7 +1043,7 @@ def main():
                         torch.cuda.empty_cache()
                         w3, _ = run_weak(a3, bl, dev, 0, 1)
                         ms3 = w3["wall"] / w3["K"] * 1e3
-                        rows["%.1f" % x_ms] = {"cycle_ms": ms3, "schedule": w3["schedule"], "deep_depth": w3.get("deep_depth"),
+                        rows["%.1f" % x_ms] = {"cycle_ms": ms3, "schedule": w3["schedule"], "deep_depth": w3.get("deep_depth"), "deep_early_handover": w3.get("deep_early_handover"),
                                                "predicted_efficiency": (w["wall"] / w["K"] * 1e3) / ms3}
                     extra["predicted_weak_efficiency"] = {
                         "by_emulated_exchange_ms": rows, "base_cycle_ms": w["wall"] / w["K"] * 1e3,
@@ -1058,7 +1068,7 @@ def main():
             "warmup": res["W"], "ms_per_step": res["wall"] / res["K"] * 1e3, "higher_is_better": True,
             "scaling": res.get("scaling", "weak"), "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": res["workload"], "brick": "8x8x8", "cells_per_gpu": res.get("cells_per_gpu", args.n ** 3),
-                       **{k: res[k] for k in ("layout", "form", "sweep_direction", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
+                       **{k: res[k] for k in ("layout", "form", "sweep_direction", "updates_per_pass", "cart", "overlap", "exchange", "schedule", "deep_depth", "deep_early_handover", "schedule_probe_ms", "sweep_probe_ms", "exchange_ms_alone", "exchange_bytes_per_rank",
                                              "remote_bytes_per_rank", "subdomains_per_rank", "conservation_rel_drift", "transport", "transport_fallback_reason", "exchange_self_check", "messages_per_exchange",
                                              "per_peer_send_bytes", "per_peer_GBps_exchange_alone", "distinct_gpus", "ranks_seen", "phases", "rccl_library",
                                              "local_ghosts", "local_link_bytes_per_rank", "swept_bricks_per_sweep", "subdomain_bricks", "storage_placement") if k in res}},

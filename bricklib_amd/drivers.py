@@ -10,7 +10,7 @@ the region ordering of BrickDecomp the three brick sets involved are plain id ra
 import torch
 
 from .brick import grid_to_device
-from .order import decomp_lists, trapezoid_lists
+from .order import last_shell_split, decomp_lists, trapezoid_lists
 from .stencils import Zigzag, apply_stencil, stencil_iters
 from .timing import marker
 
@@ -91,9 +91,13 @@ class TrapezoidLists:
         inner, shell = trapezoid_lists(d, sweeps, rows_per_block, kpair=kpair, icols=icols)
         self.inner = [grid_to_device(x, device) if x.size else None for x in inner]
         self.shell = [grid_to_device(x, device) if x.size else None for x in shell]
+        # the late pass of the LAST sweep in two parts: the surface bricks (what the next exchange sends) and the rest of its shell
+        surf, rest = last_shell_split(d, sweeps, rows_per_block, kpair=kpair, icols=icols)
+        self.last_surface = grid_to_device(surf, device)
+        self.last_rest = grid_to_device(rest, device) if rest.size else None
 
 
-def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, comm=None, depth=None, full=None, zigzag=False):
+def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, comm=None, depth=None, full=None, zigzag=False, state=None):
     """Same result as weak_cycle, scheduled so that the exchange hides behind most of the cycle instead of one sweep
     (xGMI is a per-link-bound point-to-point fabric; a 512^3 subdomain sends 104 MB per exchange).  While the ghosts
     of A travel on `comm`, `main` runs the part of EVERY sweep that cannot depend on them yet -- sweep t over the bricks
@@ -103,32 +107,53 @@ def weak_cycle_deep(stencil, d, A, B, exchange, lists, coeff=None, main=None, co
     lists: TrapezoidLists(d, stencil_iters(stencil)).
     depth (1..S, default S): only the first `depth` sweeps are split this way (2*depth launches, hiding the early passes
     of those sweeps); the remaining sweeps run whole over full.all / full.domain (full: SweepLists(d)).  A shallower
-    schedule hides less exchange time and costs fewer, larger launches."""
+    schedule hides less exchange time and costs fewer, larger launches.
+    state (round 5): dict carried from one cycle to the next.  With it the late pass of the last sweep writes the surface bricks
+    first and records an event, and the NEXT cycle's exchange starts behind that event -- under the rest of that pass -- instead of
+    behind the whole cycle (the exchange reads surface bricks of A and writes ghost bricks of A; the rest of the pass writes A two
+    and more bricks inside and reads B).  Same field bit for bit."""
     S = stencil_iters(stencil)
     assert len(lists.inner) == S
     K = S if depth is None else max(1, min(int(depth), S))
     assert K == S or full is not None, "depth < ST_ITER needs the whole-sweep lists (full=SweepLists(d))"
     main = main or torch.cuda.current_stream()
     zz = Zigzag()
+    early = state is not None and comm is not None      # hand the surface of the last sweep over early
     if comm is None:
         exchange(main)
     else:
-        ev0 = torch.cuda.Event()
-        ev0.record(main)                 # A as left by the previous cycle
+        ev0 = state.pop("surface_done", None) if state is not None else None
+        if ev0 is None:
+            ev0 = torch.cuda.Event()
+            ev0.record(main)             # A as left by the previous cycle
         comm.wait_event(ev0)
         exchange(comm)
         ev1 = torch.cuda.Event()
         ev1.record(comm)
+
+    def surface_first(src, dst, surface, rest, kpaired):
+        apply_stencil(stencil, src, dst, ids=surface, coeff=coeff, stream=main, kpaired=kpaired, reverse=zigzag and zz.turn())
+        ev = torch.cuda.Event()
+        ev.record(main)
+        state["surface_done"] = ev
+        if rest is not None:
+            apply_stencil(stencil, src, dst, ids=rest, coeff=coeff, stream=main, kpaired=kpaired, reverse=zigzag and zz.turn())
+
     for ids in (lists.inner, lists.shell):
         src, dst = A, B
         for t in range(K):
-            if ids[t] is not None:
+            if early and ids is lists.shell and t == S - 1:
+                surface_first(src, dst, lists.last_surface, lists.last_rest, lists.kpaired)
+            elif ids[t] is not None:
                 apply_stencil(stencil, src, dst, ids=ids[t], coeff=coeff, stream=main, kpaired=lists.kpaired, reverse=zigzag and zz.turn())
             src, dst = dst, src
         if comm is not None and ids is lists.inner:
             main.wait_event(ev1)
     for t in range(K, S):   # sweeps K+1..S whole; src/dst continue the ping-pong (sweep t+1 reads what sweep t wrote)
-        apply_stencil(stencil, src, dst, ids=full.domain if t == S - 1 else full.all, coeff=coeff, stream=main, kpaired=full.kpaired,
-                      reverse=zigzag and zz.turn())
+        if early and t == S - 1:
+            surface_first(src, dst, full.surface, full.inner, full.kpaired)
+        else:
+            apply_stencil(stencil, src, dst, ids=full.domain if t == S - 1 else full.all, coeff=coeff, stream=main, kpaired=full.kpaired,
+                          reverse=zigzag and zz.turn())
         src, dst = dst, src
     return S

@@ -191,3 +191,20 @@ def trapezoid_lists(d, sweeps, rows_per_block=8, kpair=False, icols=0):
         inner.append(tiled(_box(g, ilo, ihi), rows_per_block, kpair=kpair, icols=icols) if has else np.zeros(0, dtype=np.uint32))
         shell.append(shell_list(g, lo, hi, ilo, ihi, rows_per_block, kpair, icols))
     return inner, shell
+
+
+def last_shell_split(d, sweeps, rows_per_block=8, kpair=False, icols=0):
+    """The late pass of the LAST sweep of the deep schedule (trapezoid_lists: shell[sweeps-1] = bricks with 1 <= L <= sweeps) in two
+    parts: (surface, rest) = (L == 1: the bricks the next exchange sends, L in [2, sweeps]).  drivers.weak_cycle_deep sweeps the
+    surface first so that the next exchange can start under the rest."""
+    g = np.asarray(d.grid).astype(np.uint32)
+    T = [g.shape[2], g.shape[1], g.shape[0]]
+    t = sweeps
+    ilo, ihi = [t + 1] * 3, [T[a] - t - 1 for a in range(3)]
+    lo1, hi1 = [1] * 3, [T[a] - 1 for a in range(3)]
+    lo2, hi2 = [2] * 3, [T[a] - 2 for a in range(3)]
+    surface = shell_list(g, lo1, hi1, lo2, hi2, rows_per_block, kpair, icols)
+    if any(hi2[a] <= lo2[a] for a in range(3)):
+        return surface, np.zeros(0, dtype=np.uint32)
+    rest = shell_list(g, lo2, hi2, ilo, ihi, rows_per_block, kpair, icols)
+    return surface, rest

@@ -603,7 +603,7 @@ def test_weak_cycle_overlap_streams_single_rank(oracle, dev):
     bl.populate(d, [1, 1, 1], [0, 0, 0])
     info = d.getBrickInfo(dev)
     res = []
-    for mode in ("plain", "overlap", "deep", "deep3"):
+    for mode in ("plain", "overlap", "deep", "deep3", "deep_early", "deep3_early"):
         torch.manual_seed(3)
         stA, stB = info.allocate(512, dev), info.allocate(512, dev)
         stA.dat.uniform_(0.0, 1.0)
@@ -618,6 +618,10 @@ def test_weak_cycle_overlap_streams_single_rank(oracle, dev):
                 weak_cycle_deep("mpi7pt", d, A, B, ex.exchange, deep, main=main, comm=comm)
             elif mode == "deep3":
                 weak_cycle_deep("mpi7pt", d, A, B, ex.exchange, deep, main=main, comm=comm, depth=3, full=lists)
+            elif mode == "deep_early":       # round 5: the next exchange starts under the rest of the last late pass (state carried over)
+                weak_cycle_deep("mpi7pt", d, A, B, ex.exchange, deep, main=main, comm=comm, state=state)
+            elif mode == "deep3_early":
+                weak_cycle_deep("mpi7pt", d, A, B, ex.exchange, deep, main=main, comm=comm, depth=3, full=lists, state=state)
             else:
                 weak_cycle("mpi7pt", d, A, B, ex.exchange, main=main, comm=comm, overlap=True, lists=lists, state=state)
         torch.cuda.synchronize()
@@ -1201,7 +1205,7 @@ def test_weak_cycle_baseline_size_512(oracle, dev):
                     stA.dat.copy_(init)
                     stB.dat.zero_()
                     if schedule == "deep":
-                        weak_cycle_deep(name, d, A, B, ex.exchange, deep, main=main, comm=xs)
+                        weak_cycle_deep(name, d, A, B, ex.exchange, deep, main=main, comm=xs, state={})
                     else:
                         weak_cycle(name, d, A, B, ex.exchange, main=main, comm=xs, overlap=schedule == "surface", lists=lists, state={})
                     torch.cuda.synchronize()

@@ -366,6 +366,27 @@ def test_deep_schedule_dataflow(dom, sweeps):
     assert sweeps % 2 == 0 and (ver["A"][1:sep1] == sweeps).all()
 
 
+@pytest.mark.parametrize("dom,sweeps", [((64, 48, 56), 8), ((64, 64, 64), 4), ((32, 32, 32), 8)])
+def test_deep_schedule_early_start_split(dom, sweeps):
+    """round 5, weak_cycle_deep(state=...): the late pass of the LAST sweep is cut into (surface, rest) so that the next exchange can
+    start under `rest`.  Held here: the two parts are exactly that pass's brick set; the surface part is [sep0, sep1) -- what the
+    exchange sends; `rest` writes only bricks two and more inside the ghosted grid (the exchange reads L = 1 of A and writes L = 0 of
+    A) and -- the last sweep being an even one -- reads B, not A."""
+    from bricklib_amd.order import LIST_SKIP, last_shell_split, trapezoid_lists
+    d = bl.BrickDecomp(dom)
+    _, shell = trapezoid_lists(d, sweeps)
+    surf, rest = last_shell_split(d, sweeps)
+    real = lambda x: np.sort(x[x != LIST_SKIP].astype(np.int64))
+    assert np.array_equal(real(np.concatenate([surf, rest])), real(shell[sweeps - 1]))
+    assert np.array_equal(real(surf), np.arange(d.sep_pos[0], d.sep_pos[1]))
+    T = d.grid.shape
+    kk, jj, ii = np.meshgrid(*[np.minimum(np.arange(n), n - 1 - np.arange(n)) for n in T], indexing="ij")
+    L = np.zeros(d.nbricks, dtype=np.int64)
+    L[d.grid.reshape(-1)] = np.minimum(np.minimum(kk, jj), ii).reshape(-1)
+    assert (L[real(rest)] >= 2).all() and (L[real(surf)] == 1).all()
+    assert sweeps % 2 == 0           # sweep `sweeps` reads B and writes A (weak_cycle_deep's ping-pong)
+
+
 def test_host_bookkeeping_under_address_and_ub_sanitizers(tmp_path):
     """brk_host.cpp + brk_xplan.cpp (everything in libbrk.so that is plain C++: init_grid, BrickDecomp tables, rank maps,
     exchange plans in all modes for 1..27 ranks, strong partition / getrank / Z-Morton, error paths) built with
