@@ -114,7 +114,10 @@ int brk_stencil_apply_list_kpaired(int stencil_id, const uint32_t *adj_dev, cons
  * lo = GB, cnt = NB) and the inner region [1,sep0) of a BrickDecomp (base 1, tot = cnt = inner extent, lo = 0).
  * The 7-point kernels derive the ids arithmetically in their preferred traversal order (no list is read); the other
  * stencils use an id list in that order which the library builds once per box geometry and keeps on the device (a cache of
- * 8 geometries per process; the first call for a geometry is synchronous). */
+ * 16 geometries per process; the first call for a geometry is synchronous).  BRK_MPI125 over a REGISTERED adjacency table
+ * (brk_adjacency_register) whose box has rows of a multiple of 8 bricks and only regular bricks (all 26 neighbours are the ids the
+ * numbering predicts -- checked once per box and registration, synchronously) runs the four-waves-per-SIMD kernel k_cube125_q
+ * (6 % faster at 512^3; same results to rounding); BRK_CUBE125_Q=0 in the environment keeps the general kernel (A/B runs). */
 int brk_stencil_apply_box(int stencil_id, const uint32_t *adj_dev, const double *in_dev, double *out_dev,
                           size_t step_elems, uint32_t base, const uint32_t tot_bricks[3], const uint32_t lo[3],
                           const uint32_t cnt[3], const double *coeff_host, brk_stream s);
