@@ -26,6 +26,12 @@ class PlacePartner(C.Structure):
     _fields_ = [("storage_dev", C.c_void_p), ("relation", C.c_int)]
 
 
+class ExprOp(C.Structure):
+    """brk_expr_op: one operation of a stencil given as a register program (brk_stencil_apply_expr)"""
+    _fields_ = [("code", C.c_uint32), ("dst", C.c_uint32), ("a", C.c_uint32), ("b", C.c_uint32), ("c", C.c_uint32),
+                ("offset", C.c_int32 * 3), ("imm", C.c_double)]
+
+
 class Placement(C.Structure):
     """brk_placement: what brk_storage_alloc measured while it placed a storage"""
     _fields_ = [("candidates", C.c_int), ("chosen", C.c_int), ("probe_bricks", C.c_int), ("spacer_gib", C.c_int), ("ms_chosen", C.c_double), ("ms_worst", C.c_double), ("ms_same_allocation", C.c_double)]
@@ -146,6 +152,7 @@ def _load():
     L.brk_comm_library.argtypes = []
     L.brk_adjacency_register.argtypes = [vp, C.c_uint32]
     L.brk_adjacency_release.argtypes = [vp]
+    L.brk_stencil_apply_expr.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.POINTER(ExprOp), C.c_uint32, C.c_uint32, vp]
     L.brk_finalize.argtypes = []
     L.brk_last_kernel.restype = C.c_char_p
     L.brk_last_kernel.argtypes = []
@@ -157,7 +164,7 @@ lib = _load()
 # every symbol include/brk.h declares (tests check the library exports each of them)
 ABI_SYMBOLS = [
     "brk_last_error", "brk_abi_version", "brk_stencil_radius", "brk_stencil_ncoeff", "brk_stencil_iters",
-    "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_stencil_apply_list_kpaired", "brk_stencil_apply_box", "brk_stencil_apply_range_ex", "brk_stencil_apply_list_ex", "brk_stencil_apply_box_ex", "brk_stencil_apply_taps", "brk_link_copy", "brk_array_to_brick",
+    "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_stencil_apply_list_kpaired", "brk_stencil_apply_box", "brk_stencil_apply_range_ex", "brk_stencil_apply_list_ex", "brk_stencil_apply_box_ex", "brk_stencil_apply_taps", "brk_stencil_apply_expr", "brk_link_copy", "brk_array_to_brick",
     "brk_brick_to_array", "brk_compare_brick", "brk_init_grid", "brk_decomp_build", "brk_decomp_free",
     "brk_decomp_nbricks", "brk_decomp_grid_size", "brk_decomp_tdims", "brk_decomp_sep_pos", "brk_decomp_grid",
     "brk_decomp_adj", "brk_decomp_nruns", "brk_decomp_ghost", "brk_decomp_skin", "brk_decomp_nskin",

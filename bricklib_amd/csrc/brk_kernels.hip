@@ -87,6 +87,20 @@ __global__ __launch_bounds__(64 * WPW) void k_taps(const uint32_t *__restrict__ 
   taps_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, b, tp, threadIdx.x & 63);
 }
 
+// non-linear stencil given as a register program (brk_stencil_apply_expr): one wave per brick, generic staging
+template <int R, int WPW>
+__global__ __launch_bounds__(64 * WPW) void k_expr(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
+                                                   size_t step, const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, ExprProg pg) {
+  __shared__ double lds[WPW * CubeTile<R>::ELEMS];
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t slot = wg * WPW + (threadIdx.x >> 6);
+  if (slot >= n) return;
+  const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
+  if (b == BRK_LIST_SKIP) return;
+  expr_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, b, pg, threadIdx.x & 63);
+}
+
 // star-shaped stencil given as data, radius 3 or 4 (brk_stencil_apply_taps): one wave per workgroup (27.5 KiB of LDS per wave)
 template <int R>
 __global__ __launch_bounds__(64) void k_star_taps(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
@@ -813,6 +827,48 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
   const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
   if (tp.radius == 1) hipLaunchKernelGGL((k_taps<1, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);
   else hipLaunchKernelGGL((k_taps<2, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);
+  HIP_TRY(hipGetLastError());
+  return BRK_OK;
+}
+
+extern "C" int brk_stencil_apply_expr(const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids, uint32_t first,
+                                      uint32_t n, const brk_expr_op *ops_host, uint32_t nops, uint32_t result_reg, brk_stream s) {
+  if (!adj || !in || !out || in == out) return brk_fail(BRK_EINVAL, "bad device pointers");
+  if (step < 512) return brk_fail(BRK_EINVAL, "step_elems %zu < 512", step);
+  if (!ops_host || nops == 0 || nops > (uint32_t)kMaxExprOps) return brk_fail(BRK_EINVAL, "1..%d ops expected (got %u)", kMaxExprOps, nops);
+  if (result_reg >= (uint32_t)kMaxExprRegs) return brk_fail(BRK_EINVAL, "result register %u (0..%d)", result_reg, kMaxExprRegs - 1);
+  if (n == 0) return BRK_OK;
+  // check the program: known codes, registers in range and WRITTEN before they are read (every lane starts with an undefined file)
+  ExprProg pg;
+  std::memset(&pg, 0, sizeof pg);
+  bool written[kMaxExprRegs] = {};
+  int maxabs = 0;
+  for (uint32_t t = 0; t < nops; ++t) {
+    const brk_expr_op &o = ops_host[t];
+    if (o.code >= (uint32_t)EX_NOPS) return brk_fail(BRK_EINVAL, "op %u: unknown code %u", t, o.code);
+    if (o.dst >= (uint32_t)kMaxExprRegs) return brk_fail(BRK_EINVAL, "op %u: destination register %u", t, o.dst);
+    const int nsrc = o.code == EX_TAP || o.code == EX_CONST ? 0 : (o.code == EX_NEG || o.code == EX_ABS || o.code == EX_SQRT ? 1 : (o.code == EX_SEL ? 3 : 2));
+    const uint32_t src[3] = {o.a, o.b, o.c};
+    for (int q = 0; q < nsrc; ++q)
+      if (src[q] >= (uint32_t)kMaxExprRegs || !written[src[q]]) return brk_fail(BRK_EINVAL, "op %u: source register %u is read before it is written", t, src[q]);
+    for (int a = 0; a < 3 && o.code == EX_TAP; ++a) maxabs = std::max(maxabs, o.offset[a] < 0 ? -o.offset[a] : o.offset[a]);
+    written[o.dst] = true;
+  }
+  if (!written[result_reg]) return brk_fail(BRK_EINVAL, "result register %u is never written", result_reg);
+  if (maxabs > 2) return brk_fail(BRK_EINVAL, "tap offset %d: expression stencils reach the 125-point cube (|offset| <= 2 per axis)", maxabs);
+  pg.n = (int)nops, pg.radius = maxabs > 1 ? 2 : 1, pg.result = (int)result_reg;
+  for (uint32_t t = 0; t < nops; ++t) {
+    const brk_expr_op &o = ops_host[t];
+    ExprOp &d = pg.op[t];
+    d.code = (uint8_t)o.code, d.dst = (uint8_t)o.dst, d.a = (uint8_t)o.a, d.b = (uint8_t)o.b, d.c = (uint8_t)o.c;
+    d.rel = o.code == EX_TAP ? (pg.radius == 1 ? tap_rel<1>(o.offset[0], o.offset[1], o.offset[2]) : tap_rel<2>(o.offset[0], o.offset[1], o.offset[2])) : 0;
+    d.imm = o.imm;
+  }
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
+  brk_note_kernel(pg.radius == 1 ? "k_expr<1,4>" : "k_expr<2,4>");
+  if (pg.radius == 1) hipLaunchKernelGGL((k_expr<1, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, pg);
+  else hipLaunchKernelGGL((k_expr<2, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, pg);
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

@@ -1,70 +1,64 @@
 """Stencil scripts as data.
 
-The reference describes a stencil in a small Python script (stencils/7pt.py, mpi13pt.py, ...):
+The reference describes a stencil in a small Python script (stencils/7pt.py, mpi13pt.py, cond.py ...):
     i, j, k = Index(0), Index(1), Index(2);  input = Grid("bIn", 3);  output = Grid("bOut", 3)
     calc = ConstRef("coeff[0]") * input(i, j, k) + ConstRef("coeff[1]") * input(i + 1, j, k) + ...
     output(i, j, k).assign(calc);  STENCIL = [output]
 and its code generator turns the expression into vector code (codegen/vecscatter, codegen/st/*).  Here the script is
-only *read*: it is executed against the recording stand-ins below for `st.expr` / `st.grid`, which reduce the expression
-to a list of taps (offset, coefficient expression).  Linear scripts then run through the generic kernel
-(brk_stencil_apply_taps / brklib::brick_apply_taps) or -- when they are one of the built-in stencils -- through the tuned
-kernels; anything non-linear (Func, If: cond.py) is reported as such.
+only *read*: it is executed against the recording stand-ins below for `st.expr` / `st.grid` / `st.func`, which keep the
+expression as a tree.  From the tree:
+  * a LINEAR script reduces to a list of taps (offset, coefficient expression): one of the built-in stencils -> its tuned kernel;
+    anything else inside the 125-point cube, or star-shaped up to radius 4 -> brk_stencil_apply_taps / brklib::brick_apply_taps;
+  * a NON-LINEAR script (Func("max" | "min" | "abs" | "fabs" | "sqrt" ...), comparisons, If, products of grid references: what
+    stencils/cond.py is made of; round 5) becomes a small register program (Spec.program) for brk_stencil_apply_expr /
+    brklib::brick_apply_expr -- the general path, inside the 125-point cube.
 This module is written from the script syntax alone; it shares no code with the reference's `st` package."""
 import re
 import sys
 import types
 
+_FUNCS = {"max": ("max", 2), "fmax": ("max", 2), "min": ("min", 2), "fmin": ("min", 2), "abs": ("abs", 1), "fabs": ("abs", 1),
+          "sqrt": ("sqrt", 1)}
+_CMP = {">": "gt", ">=": "ge", "<": "lt", "<=": "le", "==": "eq", "!=": "ne"}
 
-class _Lin:
-    """sum of (coefficient, offset) terms; coefficient = product of numbers and ConstRef names"""
 
-    def __init__(self, terms):
-        self.terms = terms          # [(num: float, names: tuple[str], offset: tuple[int] or None)]
+class _E:
+    """expression node: kind in tap | num | cref | neg | add | sub | mul | div | max | min | abs | sqrt | gt.. | if"""
+
+    def __init__(self, kind, args=(), value=None):
+        self.kind, self.args, self.value = kind, tuple(args), value
 
     @staticmethod
     def lift(x):
-        if isinstance(x, _Lin):
+        if isinstance(x, _E):
             return x
-        if isinstance(x, (int, float)):
-            return _Lin([(float(x), (), None)])
+        if isinstance(x, (int, float)) and not isinstance(x, bool):
+            return _E("num", value=float(x))
         raise TypeError(f"unsupported operand {x!r}")
 
-    def __add__(self, o):
-        return _Lin(self.terms + _Lin.lift(o).terms)
+    def _bin(self, kind, o, swap=False):
+        o = _E.lift(o)
+        return _E(kind, (o, self) if swap else (self, o))
 
-    __radd__ = __add__
+    def __add__(self, o): return self._bin("add", o)
+    def __radd__(self, o): return self._bin("add", o, True)
+    def __sub__(self, o): return self._bin("sub", o)
+    def __rsub__(self, o): return self._bin("sub", o, True)
+    def __mul__(self, o): return self._bin("mul", o)
+    def __rmul__(self, o): return self._bin("mul", o, True)
+    def __truediv__(self, o): return self._bin("div", o)
+    def __rtruediv__(self, o): return self._bin("div", o, True)
+    def __neg__(self): return _E("neg", (self,))
+    def __gt__(self, o): return self._bin("gt", o)
+    def __ge__(self, o): return self._bin("ge", o)
+    def __lt__(self, o): return self._bin("lt", o)
+    def __le__(self, o): return self._bin("le", o)
+    def __eq__(self, o): return self._bin("eq", o)     # noqa: the script's `==` builds a node (nodes are compared by identity here)
+    def __ne__(self, o): return self._bin("ne", o)
+    __hash__ = object.__hash__
 
-    def __neg__(self):
-        return _Lin([(-c, n, o) for c, n, o in self.terms])
-
-    def __sub__(self, o):
-        return self + (-_Lin.lift(o))
-
-    def __rsub__(self, o):
-        return _Lin.lift(o) + (-self)
-
-    def __mul__(self, o):
-        o = _Lin.lift(o)
-        out = []
-        for c1, n1, o1 in self.terms:
-            for c2, n2, o2 in o.terms:
-                if o1 is not None and o2 is not None:
-                    raise ValueError("product of two grid references: not a linear stencil")
-                out.append((c1 * c2, n1 + n2, o1 if o1 is not None else o2))
-        return _Lin(out)
-
-    __rmul__ = __mul__
-
-    def __truediv__(self, o):
-        o = _Lin.lift(o)
-        if len(o.terms) != 1 or o.terms[0][1] or o.terms[0][2] is not None:
-            raise ValueError("division by a non-numeric expression")
-        return self * (1.0 / o.terms[0][0])
-
-    def __gt__(self, o):
-        raise ValueError("comparison in a stencil expression: not a linear stencil")
-
-    __lt__ = __ge__ = __le__ = __gt__
+    def __bool__(self):
+        raise ValueError("a stencil expression has no truth value in the script: use If(cond, then, else)")
 
 
 class Index:
@@ -81,20 +75,20 @@ class Index:
 def ConstRef(text):
     text = str(text).strip()
     try:
-        return _Lin([(float(text), (), None)])
+        return _E("num", value=float(text))
     except ValueError:
-        return _Lin([(1.0, (text,), None)])
+        return _E("cref", value=text)
 
 
-class _GridRef(_Lin):
+class _GridRef(_E):
     def __init__(self, grid, offset):
-        super().__init__([(1.0, (), offset)])
-        self.grid, self.offset = grid, offset
+        super().__init__("tap", value=tuple(offset))
+        self.grid, self.offset = grid, tuple(offset)
 
     def assign(self, expr):
         if any(self.offset):
             raise ValueError("output must be written at (i, j, k)")
-        self.grid.assigned = _Lin.lift(expr)
+        self.grid.assigned = _E.lift(expr)
 
 
 class Grid:
@@ -109,40 +103,123 @@ class Grid:
             if not isinstance(ix, Index) or ix.axis != pos:
                 raise ValueError(f"grid {self.name}: argument {pos} must be Index({pos}) +/- constant")
             off[pos] = ix.shift
-        g = _GridRef(self, tuple(off))
-        g.read_of = self
-        return g
-
-
-def _nonlinear(*a, **k):
-    raise ValueError("Func/If in a stencil expression: not a linear stencil")
+        return _GridRef(self, off)
 
 
 class Func:
-    def __init__(self, *a, **k):
-        pass
+    """Func("max", 2): the reference passes the name through to C; here a fixed set is understood"""
 
-    __call__ = _nonlinear
+    def __init__(self, name, nargs=None):
+        self.name = str(name)
+        if self.name not in _FUNCS:
+            raise ValueError(f'Func("{self.name}"): functions understood in a stencil script: {", ".join(sorted(_FUNCS))}')
+        self.kind, self.nargs = _FUNCS[self.name]
+        if nargs is not None and int(nargs) != self.nargs:
+            raise ValueError(f'Func("{self.name}", {nargs}): takes {self.nargs} argument(s)')
+
+    def __call__(self, *args):
+        if len(args) != self.nargs:
+            raise ValueError(f"{self.name}: {len(args)} arguments for {self.nargs}")
+        return _E(self.kind, [_E.lift(a) for a in args])
 
 
-If = _nonlinear
+def If(cond, then, other):
+    return _E("if", (_E.lift(cond), _E.lift(then), _E.lift(other)))
+
+
+class NotLinear(ValueError):
+    pass
+
+
+def _linear_terms(e):
+    """[(number, names, offset or None)] of a linear expression; NotLinear otherwise"""
+    k = e.kind
+    if k == "tap":
+        return [(1.0, (), e.value)]
+    if k == "num":
+        return [(e.value, (), None)]
+    if k == "cref":
+        return [(1.0, (e.value,), None)]
+    if k == "neg":
+        return [(-c, n, o) for c, n, o in _linear_terms(e.args[0])]
+    if k in ("add", "sub"):
+        a, b = _linear_terms(e.args[0]), _linear_terms(e.args[1])
+        return a + ([(-c, n, o) for c, n, o in b] if k == "sub" else b)
+    if k == "mul":
+        out = []
+        for c1, n1, o1 in _linear_terms(e.args[0]):
+            for c2, n2, o2 in _linear_terms(e.args[1]):
+                if o1 is not None and o2 is not None:
+                    raise NotLinear("product of two grid references: not a linear stencil")
+                out.append((c1 * c2, n1 + n2, o1 if o1 is not None else o2))
+        return out
+    if k == "div":
+        d = _linear_terms(e.args[1])
+        if len(d) != 1 or d[0][1] or d[0][2] is not None:
+            raise NotLinear("division by a non-numeric expression: not a linear stencil")
+        return [(c / d[0][0], n, o) for c, n, o in _linear_terms(e.args[0])]
+    raise NotLinear(f"{k} in a stencil expression: not a linear stencil")
+
+
+def _resolver(constants):
+    constants = constants or {}
+
+    def value(name):
+        if name in constants:
+            return float(constants[name])
+        m = re.fullmatch(r"(\w+)\[(\d+)\]", name)
+        if m and m.group(1) in constants:
+            return float(constants[m.group(1)][int(m.group(2))])
+        raise KeyError(f"no value for constant {name!r}")
+    return value
+
+
+EX = {"tap": 0, "const": 1, "add": 2, "sub": 3, "mul": 4, "div": 5, "neg": 6, "max": 7, "min": 8, "abs": 9, "sqrt": 10, "gt": 11, "ge": 12,
+      "lt": 13, "le": 14, "eq": 15, "ne": 16, "if": 17}       # BRK_EX_* of include/brk.h
+MAX_REGS, MAX_OPS = 16, 120
 
 
 class Spec:
-    """input/output grid names and the taps of a linear 3-D stencil script"""
+    """input/output grid names of a 3-D stencil script; taps when it is linear, a register program in any case"""
 
-    def __init__(self, out_name, terms, grids):
-        self.output = out_name
-        self._terms = terms
-        reads = [t for t in terms if t[2] is not None]
-        if len(reads) != len(terms):
-            raise ValueError("constant term without a grid reference")
+    def __init__(self, out_name, expr, grids):
+        self.output, self.expr = out_name, expr
         self.input = grids[0] if grids else None
-        self.offsets = [t[2] for t in terms]
-        self.radius = max([max(abs(x) for x in o) for o in self.offsets] + [0])
+        try:
+            self._terms = _linear_terms(expr)
+            if any(t[2] is None for t in self._terms):
+                raise ValueError("constant term without a grid reference")
+            self.linear = True
+        except NotLinear as e:
+            self._terms, self.linear, self._why = None, False, str(e)
+        offs = []
+        self._walk(expr, lambda n: offs.append(n.value) if n.kind == "tap" else None, set())
+        if not offs:
+            raise ValueError("the expression reads no grid")
+        self.radius = max(max(abs(x) for x in o) for o in offs)
+        self._tap_offsets = offs
+
+    @staticmethod
+    def _walk(e, fn, seen):
+        if id(e) in seen:
+            return
+        seen.add(id(e))
+        for a in e.args:
+            Spec._walk(a, fn, seen)
+        fn(e)
+
+    def _need_linear(self):
+        if not self.linear:
+            raise ValueError(self._why)
+
+    @property
+    def offsets(self):
+        self._need_linear()
+        return [t[2] for t in self._terms]
 
     def coefficient_exprs(self):
         """C expressions of the coefficients, tap by tap (what a rewritten brick(...) line evaluates)"""
+        self._need_linear()
         out = []
         for c, names, _ in self._terms:
             parts = ([repr(c)] if c != 1.0 or not names else []) + [f"({n})" for n in names]
@@ -152,16 +229,8 @@ class Spec:
     def taps(self, constants=None):
         """[((di,dj,dk), weight)] with ConstRef names resolved through `constants`: a dict name -> value; entries
         such as "coeff" may be sequences, so "coeff[3]" resolves to constants["coeff"][3]"""
-        constants = constants or {}
-
-        def value(name):
-            if name in constants:
-                return float(constants[name])
-            m = re.fullmatch(r"(\w+)\[(\d+)\]", name)
-            if m and m.group(1) in constants:
-                return float(constants[m.group(1)][int(m.group(2))])
-            raise KeyError(f"no value for constant {name!r}")
-
+        self._need_linear()
+        value = _resolver(constants)
         out = []
         for c, names, off in self._terms:
             w = c
@@ -172,11 +241,123 @@ class Spec:
 
     def builtin(self):
         """name of the built-in stencil with exactly these offsets and coefficient expressions, if any"""
+        if not self.linear:
+            return None
         key = sorted(zip(self.offsets, self.coefficient_exprs()))
         for name, want in _BUILTIN.items():
             if key == want:
                 return name
         return None
+
+    def program(self, constants=None, as_c=False):
+        """(ops, result register): the expression as a register program for brk_stencil_apply_expr -- ops are dicts
+        {code, dst, a, b, c, offset, imm}; at most 16 registers live at a time (a sub-expression used several times, like `calc` in
+        cond.py's If(calc > 0, calc, -calc), is computed once and kept).  constants: as for taps(); as_c: `imm` of a ConstRef stays its
+        C text (what tools/brkscatter writes into a driver, where `coeff[3]` is an lvalue of the kernel)."""
+        if self.radius > 2:
+            raise ValueError(f"radius {self.radius}: expression stencils reach the 125-point cube (|offset| <= 2 per axis)")
+        value = _resolver(constants)
+        uses = {}
+
+        def count(e):
+            uses[id(e)] = uses.get(id(e), 0) + 1
+            if uses[id(e)] == 1:
+                for a in e.args:
+                    count(a)
+        count(self.expr)
+        need = {}          # Sethi-Ullman number: registers a subtree wants (shared nodes: as if unshared; only an ordering hint)
+
+        def weigh(e):
+            if id(e) in need:
+                return need[id(e)]
+            w = sorted((weigh(a) for a in e.args), reverse=True)
+            need[id(e)] = max([1] + [x + q for q, x in enumerate(w)])
+            return need[id(e)]
+        weigh(self.expr)
+        ops, loc, free = [], {}, list(range(MAX_REGS - 1, -1, -1))
+
+        def release(e):
+            uses[id(e)] -= 1
+            if uses[id(e)] == 0:
+                free.append(loc.pop(id(e)))
+
+        def gen(e):
+            if id(e) in loc:
+                return loc[id(e)]
+            order = sorted(range(len(e.args)), key=lambda q: -need[id(e.args[q])])
+            regs = {}
+            for q in order:
+                regs[q] = gen(e.args[q])
+            src = [regs[q] for q in range(len(e.args))]
+            for a in e.args:            # sources may be reused as the destination
+                release(a)
+            if not free:
+                raise ValueError(f"the expression needs more than {MAX_REGS} values at once")
+            dst = free.pop()
+            op = {"code": EX["const" if e.kind in ("num", "cref") else e.kind], "dst": dst, "a": 0, "b": 0, "c": 0, "offset": (0, 0, 0), "imm": 0.0}
+            if e.kind == "tap":
+                op["offset"] = tuple(e.value)
+            elif e.kind == "num":
+                op["imm"] = e.value
+            elif e.kind == "cref":
+                op["imm"] = f"({e.value})" if as_c else value(e.value)
+            else:
+                for name, r in zip("abc", src):
+                    op[name] = r
+            ops.append(op)
+            loc[id(e)] = dst
+            return dst
+
+        result = gen(self.expr)
+        if len(ops) > MAX_OPS:
+            raise ValueError(f"the expression compiles to {len(ops)} operations (at most {MAX_OPS})")
+        return ops, result
+
+    def evaluate(self, tap_value, constants=None):
+        """numpy evaluation of the expression: tap_value(offset) -> array of in[p + offset] over the cells wanted (the checker's side
+        of the expression path: oracle.brick_expr feeds it with the accessor's values)"""
+        import numpy as np
+        value = _resolver(constants)
+        memo = {}
+
+        def ev(e):
+            if id(e) in memo:
+                return memo[id(e)]
+            k, a = e.kind, [ev(x) for x in e.args]
+            if k == "tap":
+                r = tap_value(tuple(e.value))
+            elif k == "num":
+                r = e.value
+            elif k == "cref":
+                r = value(e.value)
+            elif k == "neg":
+                r = -a[0]
+            elif k == "add":
+                r = a[0] + a[1]
+            elif k == "sub":
+                r = a[0] - a[1]
+            elif k == "mul":
+                r = a[0] * a[1]
+            elif k == "div":
+                r = a[0] / a[1]
+            elif k == "max":
+                r = np.where(np.asarray(a[0]) > np.asarray(a[1]), a[0], a[1])
+            elif k == "min":
+                r = np.where(np.asarray(a[0]) < np.asarray(a[1]), a[0], a[1])
+            elif k == "abs":
+                r = np.where(np.asarray(a[0]) < 0, -np.asarray(a[0]), a[0])
+            elif k == "sqrt":
+                r = np.sqrt(a[0])
+            elif k in ("gt", "ge", "lt", "le", "eq", "ne"):
+                f = {"gt": np.greater, "ge": np.greater_equal, "lt": np.less, "le": np.less_equal, "eq": np.equal, "ne": np.not_equal}[k]
+                r = f(a[0], a[1]).astype(np.float64)
+            elif k == "if":
+                r = np.where(np.asarray(a[0]) != 0, a[1], a[2])
+            else:
+                raise ValueError(k)
+            memo[id(e)] = r
+            return r
+        return ev(self.expr)
 
 
 def _star(r, cname):
@@ -250,4 +431,4 @@ def load_spec(source, filename="<stencil script>"):
     if out.dims != 3:
         raise ValueError(f"{out.dims}-D stencil: only 3-D bricks are supported")
     ins = [g.name for g in made if g is not out]
-    return Spec(out.name, out.assigned.terms, ins)
+    return Spec(out.name, out.assigned, ins)

@@ -56,6 +56,27 @@ def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coef
                                              _stream(stream)))
 
 
+def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None):
+    """A stencil script as an expression (brk_stencil_apply_expr): `spec` = bricklib_amd.spec.load_spec(...) of ANY script inside the
+    125-point cube -- Func("max" / "min" / "abs" / "sqrt"), comparisons, If, products of grid references included (what the
+    reference's generator accepts; stencils/cond.py is made of these).  constants: values of the script's ConstRef names.  The
+    general path; linear scripts are better served by apply_taps / the built-in stencils."""
+    from ._lib import ExprOp
+    ops, result = spec.program(constants)
+    tab = (ExprOp * len(ops))()
+    for q, o in enumerate(ops):
+        tab[q].code, tab[q].dst, tab[q].a, tab[q].b, tab[q].c, tab[q].imm = o["code"], o["dst"], o["a"], o["b"], o["c"], float(o["imm"])
+        tab[q].offset[0], tab[q].offset[1], tab[q].offset[2] = o["offset"]
+    adj = bIn.bInfo.adj
+    if ids is not None:
+        check(lib.brk_stencil_apply_expr(_ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids), 0, ids.numel(), tab, len(ops), result,
+                                         _stream(stream)))
+    else:
+        b0, b1 = brick_range if brick_range is not None else (0, bIn.bInfo.nbricks)
+        check(lib.brk_stencil_apply_expr(_ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, None, int(b0), int(b1 - b0), tab, len(ops), result,
+                                         _stream(stream)))
+
+
 def last_kernel():
     """Name (template arguments included) of the kernel the last stencil launch of the calling thread enqueued (brk_last_kernel)."""
     return lib.brk_last_kernel().decode()

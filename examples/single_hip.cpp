@@ -6,6 +6,7 @@
 // Both are checked with compareBrick against the array sweep on the CPU, like the reference does.
 //   build: make -C examples        run: examples/single_hip [N]
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -75,6 +76,16 @@ __global__ void star37_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Br
   long ti = GB + hipBlockIdx_x;
   unsigned b = grid[tk][tj][ti];
   brick("star37.py", VSVEC, (BDIM), (VFOLD), b);
+}
+
+// ... and one that is not a sum of taps at all: examples/minmod.py (If / Func / products of grid references); tools/brkscatter writes
+// the script's operations out as straight-line code over the staged tile
+__global__ void minmod_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Brick3D bOut, bElem *coeff) {
+  long tk = GB + hipBlockIdx_z;
+  long tj = GB + hipBlockIdx_y;
+  long ti = GB + hipBlockIdx_x;
+  unsigned b = grid[tk][tj][ti];
+  brick("minmod.py", VSVEC, (BDIM), (VFOLD), b);
 }
 
 static int run() {
@@ -214,6 +225,24 @@ static int run() {
     hipLaunchKernelGGL(star37_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
     gpuCheck(hipDeviceSynchronize());
     check("brick() star37 kernel (radius-3 star script read as data)");
+  }
+  // (6) a user-written non-linear script (minmod.py): limited slopes, the script's operations as generated straight-line code
+  {
+    auto minmod = [](bElem l, bElem r) -> bElem { return l * r > 0 ? (l > 0 ? 1.0 : -1.0) * std::min(std::abs(l), std::abs(r)) : 0.0; };
+#pragma omp parallel for collapse(2)
+    for (long k = PADDING + GZ; k < PADDING + GZ + N; ++k)
+      for (long j = PADDING + GZ; j < PADDING + GZ + N; ++j)
+        for (long i = PADDING + GZ; i < PADDING + GZ + N; ++i) {
+          const bElem c = arr_in[k][j][i];
+          const bElem s = minmod(c - arr_in[k][j][i - 1], arr_in[k][j][i + 1] - c) + minmod(c - arr_in[k][j - 1][i], arr_in[k][j + 1][i] - c) +
+                          minmod(c - arr_in[k - 1][j][i], arr_in[k + 1][j][i] - c);
+          arr_out[k][j][i] = c - coeff[0] * s;
+        }
+    Brick3D dIn(binfo_dev, bstorage_dev, 0), dOut(binfo_dev, bstorage_dev, bsize);
+    dim3 block(NB, NB, NB), thread(64);
+    hipLaunchKernelGGL(minmod_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
+    gpuCheck(hipDeviceSynchronize());
+    check("brick() minmod kernel (non-linear script, generated straight-line code)");
   }
   return 0;
 }

@@ -772,6 +772,93 @@ __device__ __forceinline__ void brick_apply_taps_static(const uint32_t *adj, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// NON-LINEAR stencils given as data (round 5): the reference's generator takes any expression over grid references, constants,
+// functions and If (codegen/st/codegen/base.py:678; stencils/cond.py uses max and If).  Here such a script arrives as a small
+// register program (bricklib_amd/spec.py reduces the script to it; tools/brkscatter writes it next to a rewritten brick(...) line):
+// every op names a destination register, up to three source registers, an immediate or a tap.  One wave stages the brick with its
+// radius-R halo (cube_stage) and every lane runs the program once per k-plane; the op loop is wave-uniform, the register file is a
+// per-lane array indexed by uniform values.  The general path: one LDS read per tap, a handful of instructions per op.
+// ---------------------------------------------------------------------------------------------------------------
+enum { EX_TAP = 0, EX_CONST, EX_ADD, EX_SUB, EX_MUL, EX_DIV, EX_NEG, EX_MAX, EX_MIN, EX_ABS, EX_SQRT, EX_GT, EX_GE, EX_LT, EX_LE, EX_EQ, EX_NE, EX_SEL, EX_NOPS };
+constexpr int kMaxExprOps = 120, kMaxExprRegs = 16;
+struct ExprOp {
+  uint8_t code, dst, a, b, c, pad_[3];
+  int32_t rel; // EX_TAP: offset of the tap relative to the centre cell inside a CubeTile<R> (tap_rel<R>)
+  double imm;  // EX_CONST
+};
+struct ExprProg {
+  int32_t n, radius, result, pad_;
+  ExprOp op[kMaxExprOps];
+};
+static_assert(sizeof(ExprProg) <= 3072, "the program travels as a kernel argument");
+
+template <int R>
+__device__ __forceinline__ void expr_brick(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
+                                           size_t step, uint32_t b, const ExprProg &pg, int lane) {
+  using TL = CubeTile<R>;
+  const int hi = lane >> 3, lo = lane & 7;
+  cube_stage<R>(tile, adj, in, step, b, lane);
+  const double *c = tile + TL::at(R, hi + R, lo + R);
+  double *dst = out + (size_t)b * step;
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    double reg[kMaxExprRegs];
+#pragma unroll 1
+    for (int t = 0; t < pg.n; ++t) {
+      const ExprOp o = pg.op[t];
+      const double x = reg[o.a & (kMaxExprRegs - 1)], y = reg[o.b & (kMaxExprRegs - 1)], z = reg[o.c & (kMaxExprRegs - 1)];
+      double v;
+      switch (o.code) { // wave-uniform
+      case EX_TAP: v = c[k * TL::T * TL::P + o.rel]; break;
+      case EX_CONST: v = o.imm; break;
+      case EX_ADD: v = x + y; break;
+      case EX_SUB: v = x - y; break;
+      case EX_MUL: v = x * y; break;
+      case EX_DIV: v = x / y; break;
+      case EX_NEG: v = -x; break;
+      case EX_MAX: v = x > y ? x : y; break; // the C macro / fmax of the reference's generated code on ordered values
+      case EX_MIN: v = x < y ? x : y; break;
+      case EX_ABS: v = x < 0 ? -x : x; break;
+      case EX_SQRT: v = __builtin_sqrt(x); break;
+      case EX_GT: v = x > y ? 1.0 : 0.0; break;
+      case EX_GE: v = x >= y ? 1.0 : 0.0; break;
+      case EX_LT: v = x < y ? 1.0 : 0.0; break;
+      case EX_LE: v = x <= y ? 1.0 : 0.0; break;
+      case EX_EQ: v = x == y ? 1.0 : 0.0; break;
+      case EX_NE: v = x != y ? 1.0 : 0.0; break;
+      default: v = x != 0.0 ? y : z; break; // EX_SEL: If(cond, then, else)
+      }
+      reg[o.dst & (kMaxExprRegs - 1)] = v;
+    }
+    store_result(&dst[k * 64 + lane], reg[pg.result & (kMaxExprRegs - 1)]);
+  }
+}
+
+// user-kernel entry point (what tools/brkscatter emits for a non-linear stencil script)
+template <int R, int MAXW = 4>
+__device__ __forceinline__ void brick_apply_expr(const uint32_t *adj, const double *in, double *out, size_t step, uint32_t b, const ExprProg &pg) {
+  __shared__ double lds[MAXW * CubeTile<R>::ELEMS];
+  expr_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, __builtin_amdgcn_readfirstlane(b), pg, threadIdx.x & 63);
+}
+
+// The same with the expression known at compile time (what tools/brkscatter emits for a non-linear stencil script: the script's operations
+// written out as straight-line C++ in a lambda).  f(c): the value of one cell, c = the cell's own position in the staged tile, a
+// grid reference in[p + (di, dj, dk)] is c[tap_rel<R>(di, dj, dk)].
+template <int R, int MAXW = 4, class F>
+__device__ __forceinline__ void brick_apply_fn(const uint32_t *adj, const double *in, double *out, size_t step, uint32_t b, F f) {
+  using TL = CubeTile<R>;
+  __shared__ double lds[MAXW * TL::ELEMS];
+  const int lane = threadIdx.x & 63, hi = lane >> 3, lo = lane & 7;
+  double *tile = lds + (threadIdx.x >> 6) * TL::ELEMS;
+  b = __builtin_amdgcn_readfirstlane(b);
+  cube_stage<R>(tile, adj, in, step, b, lane);
+  const double *c = tile + TL::at(R, hi + R, lo + R);
+  double *dst = out + (size_t)b * step;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], f(c + k * TL::T * TL::P));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // STAR-shaped stencils given as data, radius up to 4: every tap moves along ONE axis (what a user-written radius-3 or
 // radius-4 finite-difference script is; the reference's generator takes any script, codegen/st/codegen/base.py:678).  Staging
 // as star_brick (k-column in registers, TJ / TI sub-tiles); with taps known only at run time the k-column goes to LDS as

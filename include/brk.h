@@ -63,7 +63,7 @@ const char *brk_last_error(void);
  * 1003: the ghost-zone exchange: brk_xplan_*, brk_exchange_*, brk_comm_*; 1004: brk_adjacency_register / _release;
  * 1005: brk_stencil_apply_{range,list,box}_ex with BRK_SWEEP_* flags; 1006: brk_comm_library, the development knob
  * brk_set_variant is no longer part of the ABI; 1007: brk_storage_alloc / brk_storage_free / brk_placement_probe;
- * 1008: brk_finalize, brk_last_kernel; 1009: brk_storage_alloc_ex) */
+ * 1008: brk_finalize, brk_last_kernel; 1009: brk_storage_alloc_ex; 1010: brk_stencil_apply_expr) */
 int brk_abi_version(void);
 /* Orderly end of the library's use of the GPU before a process leaves main(): waits for everything enqueued on the current device
  * and releases, on the CALLING thread, what the library itself holds there (box id lists and their events, derived tables of
@@ -166,6 +166,22 @@ int brk_adjacency_release(const uint32_t *adj_dev);
 int brk_stencil_apply_taps(const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
                            const uint32_t *brick_ids_dev, uint32_t first, uint32_t n, uint32_t ntaps,
                            const int32_t *offsets_host, const double *weights_host, brk_stream s);
+
+/* NON-LINEAR stencils given as data (ABI 1010): the reference's generator takes any expression over grid references, constants,
+ * functions and If (codegen/st/codegen/base.py:678; stencils/cond.py: max, If).  A script arrives as a register program
+ * (bricklib_amd/spec.py builds it from the script; at most 120 ops, 16 registers, taps inside the 125-point cube): out[p] =
+ * value of register `result_reg` after the ops have run in order for cell p.  Registers must be written before they are read.
+ * The general path -- one LDS read per tap, a few instructions per op; the built-in stencils keep their tuned kernels. */
+enum { BRK_EX_TAP = 0, BRK_EX_CONST, BRK_EX_ADD, BRK_EX_SUB, BRK_EX_MUL, BRK_EX_DIV, BRK_EX_NEG, BRK_EX_MAX, BRK_EX_MIN, BRK_EX_ABS,
+       BRK_EX_SQRT, BRK_EX_GT, BRK_EX_GE, BRK_EX_LT, BRK_EX_LE, BRK_EX_EQ, BRK_EX_NE, BRK_EX_SEL /* dst = a != 0 ? b : c */ };
+typedef struct {
+  uint32_t code, dst, a, b, c; /* BRK_EX_*; destination and source registers (0..15) */
+  int32_t offset[3];           /* BRK_EX_TAP: (di, dj, dk), contiguous axis first */
+  double imm;                  /* BRK_EX_CONST */
+} brk_expr_op;
+int brk_stencil_apply_expr(const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
+                           const uint32_t *brick_ids_dev /* NULL: id range */, uint32_t first, uint32_t n,
+                           const brk_expr_op *ops_host, uint32_t nops, uint32_t result_reg, brk_stream s);
 /* Development builds of the library (make -C bricklib_amd/csrc DEV=1 or VARIANTS=1) additionally export the experiment knobs
  * used by tools/kbench (kernel variant selection, LDS padding, diagnostic modes), looked up with dlsym.  They are not declared
  * here and the default libbrk.so does not contain them: not part of this ABI. */

@@ -162,6 +162,23 @@ class Oracle:
         w = np.ascontiguousarray([x for _, x in taps], dtype=np.float64)
         self.L.orc_brick_taps(adj, bin_, bout, step, ids, ids.size, len(taps), off, w)
 
+    def brick_expr(self, spec, adj, bin_, bout, step, ids, constants=None):
+        """A stencil script as an EXPRESSION (bricklib_amd.spec.Spec: Func / If / products allowed; what the reference's generator
+        accepts, codegen/st/codegen/base.py:678) evaluated cell by cell with the accessor's neighbour semantics: every grid reference
+        in[p + offset] is gathered with orc_brick_taps (one tap of weight 1: exactly the value), the tree is evaluated in numpy.
+        The checker of brk_stencil_apply_expr."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        cache = {}
+
+        def tap(off):
+            if off not in cache:
+                tmp = np.zeros_like(bin_)
+                self.brick_taps(adj, bin_, tmp, step, ids, [(off, 1.0)])
+                cache[off] = tmp.reshape(-1, step)[ids][:, :512]
+            return cache[off]
+        val = np.broadcast_to(np.asarray(spec.evaluate(tap, constants), dtype=np.float64), (ids.size, 512))
+        bout.reshape(-1, step)[ids, :512] = val
+
     def brick_stencil_naive(self, sid, adj, bin_, bout, step, ids, coeff=None):
         cp = _coeff(coeff)
         ids = np.ascontiguousarray(ids, dtype=np.uint32)

@@ -168,6 +168,66 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
     }
     return;
   }
+  if (name.find("k_expr<") != std::string::npos) { // (adj, in, out, step, ids, first, n, ExprProg): every tap gathered by the oracle, the ops interpreted per cell
+    const uint32_t *adj = arg<const uint32_t *>(args, 0);
+    const double *in = arg<const double *>(args, 1);
+    double *out = arg<double *>(args, 2);
+    const size_t step = arg<size_t>(args, 3);
+    const brklib::ExprProg pg = arg<brklib::ExprProg>(args, 7);
+    const int R = (int)targs(name, "k_expr").at(0);
+    if (pg.radius != R || pg.n < 1 || pg.n > brklib::kMaxExprOps) abort();
+    const std::vector<uint32_t> list = checked_list(adj, in, out, step, arg<const uint32_t *>(args, 4), arg<uint32_t>(args, 5), arg<uint32_t>(args, 6));
+    if (list.empty()) return;
+    uint32_t top = 0;
+    for (uint32_t b : list) top = std::max(top, b);
+    std::map<int, std::vector<double>> gathered; // rel -> in[p + offset] over the listed bricks (laid out like `out`)
+    for (int t = 0; t < pg.n; ++t) {
+      if (pg.op[t].code != brklib::EX_TAP || gathered.count(pg.op[t].rel)) continue;
+      int off[3] = {9, 9, 9};
+      for (int dk = -R; dk <= R; ++dk)
+        for (int dj = -R; dj <= R; ++dj)
+          for (int di = -R; di <= R; ++di)
+            if ((R == 1 ? brklib::tap_rel<1>(di, dj, dk) : brklib::tap_rel<2>(di, dj, dk)) == pg.op[t].rel) off[0] = di, off[1] = dj, off[2] = dk;
+      if (off[0] == 9) abort();
+      std::vector<double> &g = gathered[pg.op[t].rel];
+      g.assign(((size_t)top + 1) * step, 0.0);
+      const double one = 1.0;
+      orc_brick_taps(adj, in, g.data(), step, list.data(), (long)list.size(), 1, off, &one);
+    }
+    for (uint32_t b : list)
+      for (int cell = 0; cell < 512; ++cell) {
+        double reg[brklib::kMaxExprRegs] = {};
+        for (int t = 0; t < pg.n; ++t) {
+          const brklib::ExprOp &o = pg.op[t];
+          const double x = reg[o.a], y = reg[o.b], z = reg[o.c];
+          double v = 0;
+          switch (o.code) {
+          case brklib::EX_TAP: v = gathered[o.rel][(size_t)b * step + cell]; break;
+          case brklib::EX_CONST: v = o.imm; break;
+          case brklib::EX_ADD: v = x + y; break;
+          case brklib::EX_SUB: v = x - y; break;
+          case brklib::EX_MUL: v = x * y; break;
+          case brklib::EX_DIV: v = x / y; break;
+          case brklib::EX_NEG: v = -x; break;
+          case brklib::EX_MAX: v = x > y ? x : y; break;
+          case brklib::EX_MIN: v = x < y ? x : y; break;
+          case brklib::EX_ABS: v = x < 0 ? -x : x; break;
+          case brklib::EX_SQRT: v = std::sqrt(x); break;
+          case brklib::EX_GT: v = x > y; break;
+          case brklib::EX_GE: v = x >= y; break;
+          case brklib::EX_LT: v = x < y; break;
+          case brklib::EX_LE: v = x <= y; break;
+          case brklib::EX_EQ: v = x == y; break;
+          case brklib::EX_NE: v = x != y; break;
+          case brklib::EX_SEL: v = x != 0 ? y : z; break;
+          default: abort();
+          }
+          reg[o.dst] = v;
+        }
+        out[(size_t)b * step + cell] = reg[pg.result];
+      }
+    return;
+  }
   if (name.find("k_star_taps<") != std::string::npos) { // (adj, in, out, step, ids, first, n, StarTaps)
     const brklib::StarTaps t = arg<brklib::StarTaps>(args, 7);
     std::vector<int> off;

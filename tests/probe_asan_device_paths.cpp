@@ -198,6 +198,24 @@ static int launches() {
     const int32_t cube3[] = {3, 1, 0};
     REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 1, 1, cube3, w, nullptr) != BRK_OK);
   }
+  // stencil given as a register program: |max(in, 0) * in(i+2, j-1, k+1) - 0.5|, then the argument checks
+  {
+    brk_expr_op ops[7] = {};
+    ops[0].code = BRK_EX_TAP, ops[0].dst = 0;
+    ops[1].code = BRK_EX_CONST, ops[1].dst = 1, ops[1].imm = 0.0;
+    ops[2].code = BRK_EX_MAX, ops[2].dst = 0, ops[2].a = 0, ops[2].b = 1;
+    ops[3].code = BRK_EX_TAP, ops[3].dst = 1, ops[3].offset[0] = 2, ops[3].offset[1] = -1, ops[3].offset[2] = 1;
+    ops[4].code = BRK_EX_MUL, ops[4].dst = 0, ops[4].a = 0, ops[4].b = 1;
+    ops[5].code = BRK_EX_CONST, ops[5].dst = 1, ops[5].imm = 0.5;
+    ops[6].code = BRK_EX_SUB, ops[6].dst = 2, ops[6].a = 0, ops[6].b = 1;
+    REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 3, ops, 7, 2, nullptr) == BRK_OK);
+    REQ(std::string(brk_last_kernel()) == "k_expr<2,4>");
+    REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 0, 3, ops, 7, 3, nullptr) != BRK_OK); // register 3 is never written
+    ops[4].b = 9;
+    REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 0, 3, ops, 7, 2, nullptr) != BRK_OK); // read before written
+    ops[4].b = 1, ops[3].offset[2] = 3;
+    REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 0, 3, ops, 7, 2, nullptr) != BRK_OK); // outside the 125-point cube
+  }
   // array <-> brick, compare
   {
     const long dl[3] = {40, 32, 56}, pad[3] = {0, 0, 0}, gh[3] = {8, 8, 8};

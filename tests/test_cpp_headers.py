@@ -2,6 +2,7 @@
 driver (examples/single_hip.cpp: unchanged brick(...) line + C ABI) runs on the GPU."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -95,6 +96,54 @@ def test_unrewritten_brick_macro_fails_to_compile(tmp_path):
     assert r.returncode != 0 and b"brkscatter" in r.stderr
 
 
+def test_nonlinear_script_becomes_straight_line_code(tmp_path):
+    """tools/brkscatter on a NON-LINEAR user script (examples/minmod.py: If / Func / products of grid references): the tile(...) form is
+    plain loops, so the rewritten file is compiled for the HOST here (lanes = one thread) and its numbers compared bit for bit with
+    bricklib_amd.spec's evaluation of the same tree; the brick(...) form must come out as a brick_apply_fn call."""
+    import ctypes as C
+    import shutil
+    from bricklib_amd.spec import load_spec
+    shutil.copy(os.path.join(ROOT, "examples", "minmod.py"), tmp_path / "minmod.py")
+    src = tmp_path / "t.cpp"
+    src.write_text("""#include "vecscatter.h"
+#define bIn(a, b, c) in[c][b][a]
+#define bOut(a, b, c) out[c][b][a]
+#ifndef BRK_SCATTER_PASS
+static const long hipThreadIdx_x = 0, hipBlockDim_x = 1;
+#endif
+extern "C" void run(const double (*in)[12][12], double (*out)[12][12], const double *coeff) {
+  long i = 2, j = 2, k = 2;
+  tile("minmod.py", "HIP", (8, 8, 8), ("k", "j", "i"));
+}
+#ifdef WITH_BRICK
+struct B { struct { unsigned (*adj)[27]; } *bInfo; double *dat; unsigned long step; };
+__global__ void kern(B bIn, B bOut, const double *coeff, unsigned b) { brick("minmod.py", "HIP", (8, 8, 8), (8, 8), b); }
+#endif
+""")
+    out = tmp_path / "t-out.cpp"
+    tool = os.path.join(ROOT, "tools", "brkscatter")
+    r = subprocess.run([sys.executable, tool, str(src), str(out), "--", "-I" + os.path.join(ROOT, "include")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0 and b"0 brick(...) and 1 tile(...)" in r.stdout, r.stdout.decode()
+    so = tmp_path / "t.so"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), str(out), "-o", str(so)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    rng = np.random.default_rng(5)
+    a = rng.random((12, 12, 12)) - 0.5
+    got = np.zeros_like(a)
+    coeff = np.array([0.37])
+    lib = C.CDLL(str(so))
+    lib.run(a.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), coeff.ctypes.data_as(C.c_void_p))
+    spec = load_spec(str(tmp_path / "minmod.py"))
+    want = spec.evaluate(lambda o: a[2 + o[2]:10 + o[2], 2 + o[1]:10 + o[1], 2 + o[0]:10 + o[0]], {"coeff": coeff})
+    assert np.array_equal(got[2:10, 2:10, 2:10], want) and np.unique(want).size > 400 and not got[:2].any()
+    r = subprocess.run([sys.executable, tool, str(src), str(out), "--", "-DWITH_BRICK", "-I" + os.path.join(ROOT, "include")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    assert r.returncode == 0 and b"1 brick(...) and 1 tile(...)" in r.stdout, r.stdout.decode()
+    text = out.read_text()
+    assert "::brklib::brick_apply_fn<1>(" in text and "(coeff[0])" in text and 'brick("minmod.py"' not in text
+
+
 REF = "/root/reference"
 REF_EXE = os.path.join(ROOT, "examples", "_ref", "single_hip_ref")
 
@@ -159,6 +208,7 @@ def test_example_driver_runs():
     assert "brick() cond kernel: result match" in out, out
     assert "brick() lap19 kernel (script read as data): result match" in out, out   # user-written script, generic tap path
     assert "brick() star37 kernel (radius-3 star script read as data): result match" in out, out   # beyond the 125-point cube: star path
+    assert "brick() minmod kernel (non-linear script, generated straight-line code): result match" in out, out  # If / Func / products
     out2 = subprocess.run([os.path.join(ROOT, "examples", "dev_shl_check")], check=True, stdout=subprocess.PIPE).stdout.decode()
     assert "dev_shl: ok" in out2, out2
 
@@ -304,7 +354,7 @@ def test_cmake_vstarget_hook_and_library_names(tmp_path):
     r = subprocess.run(["cmake", "--build", str(b)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
-    assert "[VS][single_hip_cmake]" in out and "4 brick(...) and 0 tile(...) call(s) rewritten" in out
+    assert "[VS][single_hip_cmake]" in out and "5 brick(...) and 0 tile(...) call(s) rewritten" in out
     assert (b / "single_hip_cmake").exists()
     txt = open(os.path.join(ROOT, "CMakeLists.txt")).read()
     for name in ("brick", "brick-mpi", "brickhelper"):

@@ -915,6 +915,124 @@ def test_stencil_given_as_taps(oracle, dev, case):
     assert np.abs(B.dat.cpu().numpy() - want2).max() <= TOL
 
 
+EXPR_HEAD = """
+from st.expr import Index, ConstRef, If
+from st.grid import Grid
+from st.func import Func
+i = Index(0); j = Index(1); k = Index(2)
+"""
+EXPR_SCRIPTS = {
+    # the shape of the reference's stencils/cond.py, term order of its 7-point loop (3axis.cpp:104-111)
+    "cond": EXPR_HEAD + """
+pos = Func("max", 2)
+u = Grid("in", 3); v = Grid("out", 3)
+c = [ConstRef("coeff[%d]" % q) for q in range(7)]
+zero = ConstRef("0.0")
+total = None
+for q, (di, dj, dk) in ((5, (0, 0, 1)), (6, (0, 0, -1)), (3, (0, 1, 0)), (4, (0, -1, 0)), (1, (1, 0, 0)), (2, (-1, 0, 0)), (0, (0, 0, 0))):
+    term = c[q] * pos(u(i + di, j + dj, k + dk), zero)
+    total = term if total is None else total + term
+v(i, j, k).assign(If(total > 0, total, -total))
+STENCIL = [v]
+""",
+    # a flux limiter: products of grid references, min / abs / comparisons, radius 2, taps off the axes
+    "limiter": EXPR_HEAD + """
+lo = Func("min", 2); mag = Func("fabs", 1)
+u = Grid("u", 3); v = Grid("v", 3)
+dl = u(i, j, k) - u(i - 1, j, k); dr = u(i + 1, j, k) - u(i, j, k)
+far = u(i + 2, j - 1, k) * u(i - 2, j, k + 2) - u(i, j + 2, k - 2)
+slope = If(dl * dr > 0, lo(mag(dl), mag(dr)), 0.0)
+v(i, j, k).assign(u(i, j, k) + ConstRef("cfl") * slope * If(far >= 0, 1.0, -1.0))
+STENCIL = [v]
+""",
+    # division and square root
+    "norm": EXPR_HEAD + """
+root = Func("sqrt", 1)
+u = Grid("u", 3); v = Grid("v", 3)
+gx = u(i + 1, j, k) - u(i - 1, j, k); gy = u(i, j + 1, k) - u(i, j - 1, k); gz = u(i, j, k + 1) - u(i, j, k - 1)
+v(i, j, k).assign(u(i, j, k) / (ConstRef("eps") + root(gx * gx + gy * gy + gz * gz)))
+STENCIL = [v]
+""",
+}
+
+
+@pytest.mark.parametrize("case", ["cond", "limiter", "norm"])
+def test_stencil_given_as_expression(oracle, dev, case):
+    """brk_stencil_apply_expr (non-linear scripts: Func / If / products, what stencils/cond.py is made of): list (with
+    skipped entries) and range forms against the oracle's evaluation of the same tree with the accessor's neighbour semantics.  The
+    interpreter does the script's operations one by one in fp64 (no contraction across operations), so +, -, *, max, min, abs, If
+    agree BIT FOR BIT; / and sqrt within 2 ulp.  The cond-shaped script also against the tuned built-in kernel."""
+    from bricklib_amd.order import LIST_SKIP, tiled
+    from bricklib_amd.spec import load_spec
+    spec = load_spec(EXPR_SCRIPTS[case])
+    coeff = oracle.coeffs(129, 1) - 0.45           # both signs: both arms of cond's If are taken
+    consts = {"coeff": coeff, "cfl": 0.3, "eps": 1e-3}
+    assert not spec.linear
+
+    def agree(got, want):
+        if case == "norm":
+            assert np.abs(got - want).max() <= 4e-16 * np.abs(want).max() and np.abs(want).max() > 1
+        else:
+            assert np.array_equal(got, want) and np.unique(want).size > 1000
+
+    grid, info = bl.init_grid((9, 7, 6), dev)
+    st = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    st.dat.uniform_(-0.5, 0.5)
+    so = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    lst = tiled(grid.reshape(6, 7, 9)[1:-1, 1:-1, 1:-1])
+    assert (lst == LIST_SKIP).any()
+    bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, so, 0), ids=grid_to_device(lst, dev), constants=consts)
+    assert bl.last_kernel() == ("k_expr<2,4>" if spec.radius == 2 else "k_expr<1,4>")
+    hin = st.dat.cpu().numpy()
+    want = np.zeros_like(hin)
+    real = lst[lst != LIST_SKIP]
+    oracle.brick_expr(spec, info.adj_host, hin, want, 512, real, consts)
+    agree(so.dat.cpu().numpy(), want)
+    if case == "cond":
+        sb = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+        bl.apply_stencil("cond", bl.Brick(info, st, 0), bl.Brick(info, sb, 0), ids=grid_to_device(lst, dev), coeff=coeff)
+        assert (sb.dat - so.dat).abs().max().item() <= TOL
+    # range form over a BrickDecomp numbering incl. the ghost ring (neighbours that are the dummy brick 0)
+    d = bl.BrickDecomp((24, 16, 32))
+    dinfo = d.getBrickInfo(dev)
+    A, B = dinfo.allocate(512, dev), dinfo.allocate(512, dev)
+    A.dat.uniform_(-0.5, 0.5)
+    A.dat[:512] = 0
+    bl.apply_expr(spec, bl.Brick(dinfo, A, 0), bl.Brick(dinfo, B, 0), brick_range=(1, d.sep_pos[2]), constants=consts)
+    hin2 = A.dat.cpu().numpy()
+    want2 = np.zeros_like(hin2)
+    oracle.brick_expr(spec, d.adj, hin2, want2, 512, np.arange(1, d.sep_pos[2], dtype=np.uint32), consts)
+    agree(B.dat.cpu().numpy(), want2)
+
+
+def test_expression_argument_checks(dev):
+    """a program is checked before anything is launched: unknown codes, registers out of range or read before written, taps
+    outside the 125-point cube, too many operations"""
+    from bricklib_amd._lib import BrkError, ExprOp, lib
+    from bricklib_amd.brick import _ptr
+    from bricklib_amd.spec import EX
+    grid, info = bl.init_grid((4, 4, 4), dev)
+    st, so = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(2))
+
+    def run(rows, result=0, n=1):
+        tab = (ExprOp * max(1, len(rows)))()
+        for q, (code, dst, a, b, c, off, imm) in enumerate(rows):
+            tab[q].code, tab[q].dst, tab[q].a, tab[q].b, tab[q].c, tab[q].imm = code, dst, a, b, c, imm
+            tab[q].offset[0], tab[q].offset[1], tab[q].offset[2] = off
+        return lib.brk_stencil_apply_expr(_ptr(info.adj), _ptr(st.dat), _ptr(so.dat), 512, None, 0, n, tab, len(rows), result, None)
+    tap = (EX["tap"], 0, 0, 0, 0, (0, 0, 0), 0.0)
+    assert run([tap]) == 0
+    assert run([tap], n=0) == 0
+    for bad, result in (([], 0), ([(99, 0, 0, 0, 0, (0, 0, 0), 0.0)], 0), ([(EX["tap"], 16, 0, 0, 0, (0, 0, 0), 0.0)], 0),
+                        ([(EX["add"], 0, 1, 2, 0, (0, 0, 0), 0.0)], 0), ([tap, (EX["add"], 1, 0, 3, 0, (0, 0, 0), 0.0)], 1),
+                        ([(EX["tap"], 0, 0, 0, 0, (3, 0, 0), 0.0)], 0), ([tap], 5), ([tap] * 121, 0), ([tap], 16)):
+        assert run(bad, result) != 0
+    from bricklib_amd.spec import load_spec
+    with pytest.raises(BrkError):       # in == out
+        bl.apply_expr(load_spec(EXPR_SCRIPTS["cond"]), bl.Brick(info, st, 0), bl.Brick(info, st, 0), brick_range=(0, 1),
+                      constants={"coeff": [0.1] * 7})
+
+
 def test_taps_argument_checks(dev):
     from bricklib_amd._lib import BrkError
     from bricklib_amd.stencils import apply_taps

@@ -50,17 +50,133 @@ STENCIL = [v]
         s.taps({})
 
 
+NONLINEAR = [
+    'f = Func("max", 2)\ng = Grid("a", 3); h = Grid("b", 3)\nh(i, j, k).assign(f(g(i, j, k), ConstRef("0.0")))\nSTENCIL = [h]',
+    'g = Grid("a", 3); h = Grid("b", 3)\nh(i, j, k).assign(g(i, j, k) * g(i + 1, j, k))\nSTENCIL = [h]',
+    'g = Grid("a", 3); h = Grid("b", 3)\nh(i, j, k).assign(If(g(i, j, k) > 0, g(i, j, k), -g(i, j, k)))\nSTENCIL = [h]',
+    'g = Grid("a", 3); h = Grid("b", 3)\nm = Func("fmin", 2); r = Func("sqrt", 1); a = Func("fabs", 1)\n'
+    'e = r(a(g(i, j - 2, k) - g(i, j, k + 2))) / (1 + m(g(i, j, k), g(i - 1, j, k)) * g(i, j, k))\n'
+    'h(i, j, k).assign(If(e <= ConstRef("lim"), e, ConstRef("lim")))\nSTENCIL = [h]',
+]
+PRELUDE = HEAD + "from st.func import Func\nfrom st.expr import If\n"
+
+
+def run_program(ops, result, tap_value):
+    """the register program of Spec.program, interpreted the way expr_brick does (include/brick-device.h)"""
+    import numpy as np
+    from bricklib_amd.spec import EX
+    name = {v: k for k, v in EX.items()}
+    reg = {}
+    for o in ops:
+        x, y, z = (reg.get(o[q]) for q in "abc")
+        k = name[o["code"]]
+        with np.errstate(all="ignore"):
+            reg[o["dst"]] = (tap_value(o["offset"]) if k == "tap" else np.float64(o["imm"]) if k == "const" else
+                             x + y if k == "add" else x - y if k == "sub" else x * y if k == "mul" else x / y if k == "div" else
+                             -x if k == "neg" else np.where(x > y, x, y) if k == "max" else np.where(x < y, x, y) if k == "min" else
+                             np.where(x < 0, -x, x) if k == "abs" else np.sqrt(x) if k == "sqrt" else
+                             (x > y) * 1.0 if k == "gt" else (x >= y) * 1.0 if k == "ge" else (x < y) * 1.0 if k == "lt" else
+                             (x <= y) * 1.0 if k == "le" else (x == y) * 1.0 if k == "eq" else (x != y) * 1.0 if k == "ne" else
+                             np.where(x != 0, y, z))
+    return reg[result]
+
+
+@pytest.mark.parametrize("body", NONLINEAR)
+def test_nonlinear_scripts_become_register_programs(body):
+    """Func / If / products of grid references (what stencils/cond.py is made of): not a tap list, but a register program for
+    brk_stencil_apply_expr whose interpretation equals the tree's numpy evaluation bit for bit"""
+    import numpy as np
+    from bricklib_amd.spec import MAX_OPS, MAX_REGS
+    s = load_spec(PRELUDE + body)
+    assert s.linear is False and s.radius <= 2 and s.builtin() is None
+    for linear_only in (s.taps, s.coefficient_exprs):
+        with pytest.raises(ValueError, match="not a linear"):
+            linear_only()
+    ops, result = s.program({"lim": 0.75})
+    assert 0 < len(ops) <= MAX_OPS and all(0 <= o[q] < MAX_REGS for o in ops for q in ("dst", "a", "b", "c"))
+    rng = np.random.default_rng(2)
+    vals = {}
+
+    def tap(off):
+        return vals.setdefault(tuple(off), rng.random(4096) - 0.5)
+    want = s.evaluate(tap, {"lim": 0.75})
+    got = run_program(ops, result, tap)
+    assert np.array_equal(got, want) and np.isfinite(want).all() and np.unique(want).size > 100
+    text, _ = s.program(as_c=True)
+    assert all(isinstance(o["imm"], (float, int, str)) for o in text)
+
+
+def test_linear_scripts_also_compile_to_programs():
+    import numpy as np
+    s = load_spec(star_script(2, ["MPI_B0", "MPI_B1", "MPI_B2"]))
+    consts = {"MPI_B0": 0.4, "MPI_B1": 0.07, "MPI_B2": 0.03}
+    ops, result = s.program(consts)
+    rng = np.random.default_rng(3)
+    vals = {}
+
+    def tap(off):
+        return vals.setdefault(tuple(off), rng.random(512))
+    assert s.linear and np.array_equal(run_program(ops, result, tap), s.evaluate(tap, consts))
+    assert np.allclose(s.evaluate(tap, consts), sum(w * tap(o) for o, w in s.taps(consts)), rtol=1e-14)
+
+
+def test_expression_limits_are_reported():
+    wide = "g = Grid('a', 3); h = Grid('b', 3)\nf = Func('max', 2)\nh(i, j, k).assign(f(g(i + 3, j, k), g(i, j, k)))\nSTENCIL = [h]"
+    with pytest.raises(ValueError, match="125-point cube"):
+        load_spec(PRELUDE + wide).program()
+    many = "g = Grid('a', 3); h = Grid('b', 3)\nf = Func('max', 2)\ne = g(i, j, k)\n" + \
+        "for q in range(70):\n    e = f(e, g(i + q % 3 - 1, j, k)) * g(i, j + q % 5 - 2, k)\n" + "h(i, j, k).assign(e)\nSTENCIL = [h]"
+    with pytest.raises(ValueError, match="operations"):
+        load_spec(PRELUDE + many).program()
+    with pytest.raises(ValueError, match="unknown function|Func"):
+        load_spec(PRELUDE + "g = Grid('a', 3); h = Grid('b', 3)\nf = Func('erf', 1)\nh(i, j, k).assign(f(g(i, j, k)))\nSTENCIL = [h]")
+
+
 @pytest.mark.parametrize("body,msg", [
-    ('f = Func("max", 2)\ng = Grid("a", 3); h = Grid("b", 3)\nh(i, j, k).assign(f(g(i, j, k), ConstRef("0.0")))\nSTENCIL = [h]', "not a linear"),
-    ('g = Grid("a", 3); h = Grid("b", 3)\nh(i, j, k).assign(g(i, j, k) * g(i + 1, j, k))\nSTENCIL = [h]', "not a linear"),
-    ('g = Grid("a", 3); h = Grid("b", 3)\nh(i, j, k).assign(If(g(i, j, k) > 0, g(i, j, k), -g(i, j, k)))\nSTENCIL = [h]', "not a linear"),
     ('g = Grid("a", 3); h = Grid("b", 3)\nh(i + 1, j, k).assign(g(i, j, k))\nSTENCIL = [h]', "output must be written"),
     ('l = Index(3)\ng = Grid("a", 4); h = Grid("b", 4)\nh(i, j, k, l).assign(g(i, j, k, l))\nSTENCIL = [h]', "only 3-D"),
     ('g = Grid("a", 3); h = Grid("b", 3)\nh(i, j, k).assign(g(j, i, k))\nSTENCIL = [h]', "must be Index"),
 ])
 def test_unsupported_scripts_are_reported(body, msg):
     with pytest.raises(ValueError, match=msg):
-        load_spec(HEAD + "from st.func import Func\nfrom st.expr import If\n" + body)
+        load_spec(PRELUDE + body)
+
+
+COND_LIKE = PRELUDE + """
+pos = Func("max", 2)
+u = Grid("in", 3); v = Grid("out", 3)
+c = [ConstRef("coeff[%d]" % q) for q in range(7)]
+zero = ConstRef("0.0")
+total = None
+for q, (di, dj, dk) in ((5, (0, 0, 1)), (6, (0, 0, -1)), (3, (0, 1, 0)), (4, (0, -1, 0)), (1, (1, 0, 0)), (2, (-1, 0, 0)), (0, (0, 0, 0))):
+    term = c[q] * pos(u(i + di, j + dj, k + dk), zero)
+    total = term if total is None else total + term
+v(i, j, k).assign(If(total > 0, total, -total))
+STENCIL = [v]
+"""
+
+
+def test_oracle_expression_evaluation_agrees_with_the_pinned_conditional_stencil(oracle):
+    """oracle.brick_expr (the checker of the expression path) on a script of the shape of the reference's stencils/cond.py, against the
+    oracle's own d3cond restatement, which tests/test_oracle_golden.py pins against the reference's header: bit for bit (same
+    operations in the same order; coefficients of both signs so that both arms of the If are taken)"""
+    import numpy as np
+    from oracle.oracle import ST_COND7
+    grid, adj = oracle.init_grid((5, 5, 5))
+    rng = np.random.default_rng(7)
+    hin = rng.random(adj.shape[0] * 512) - 0.5
+    g3 = grid.reshape(5, 5, 5)
+    ids = np.array([g3[2, 2, 2], g3[2, 1, 3], g3[3, 3, 1]], dtype=np.uint32)
+    coeff = oracle.coeffs(129, 1) - 0.45
+    s = load_spec(COND_LIKE)
+    a, b = np.zeros_like(hin), np.zeros_like(hin)
+    oracle.brick_stencil(ST_COND7, adj, hin, a, 512, ids=ids, coeff=coeff)
+    oracle.brick_expr(s, adj, hin, b, 512, ids, {"coeff": coeff})
+    assert np.array_equal(a, b) and np.count_nonzero(b) > 1400     # (a cell whose seven taps are all negative gives 0)
+    total = np.zeros_like(hin)
+    oracle.brick_taps(adj, np.maximum(hin, 0), total, 512, ids, [(o, coeff[q]) for q, o in
+                      ((5, (0, 0, 1)), (6, (0, 0, -1)), (3, (0, 1, 0)), (4, (0, -1, 0)), (1, (1, 0, 0)), (2, (-1, 0, 0)), (0, (0, 0, 0)))])
+    assert (total < 0).any() and (total > 0).any()      # both arms of the If
 
 
 def test_oracle_tap_evaluation_agrees_with_pinned_stencils(oracle):

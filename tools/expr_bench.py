@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Time the expression path (brk_stencil_apply_expr, k_expr) on a 512^3 field: a cond-shaped script beside the tuned BRK_COND7 kernel
+and the generic tap path, a radius-2 limiter script, the minmod example.  ms per sweep, CUDA-event timed, 20 sweeps after 3 warm-ups."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bricklib_amd as bl  # noqa: E402
+from bricklib_amd.spec import load_spec  # noqa: E402
+
+HEAD = """
+from st.expr import Index, ConstRef, If
+from st.grid import Grid
+from st.func import Func
+i = Index(0); j = Index(1); k = Index(2)
+u = Grid("u", 3); v = Grid("v", 3)
+"""
+COND = HEAD + """
+pos = Func("max", 2)
+total = None
+for q, (di, dj, dk) in ((5, (0, 0, 1)), (6, (0, 0, -1)), (3, (0, 1, 0)), (4, (0, -1, 0)), (1, (1, 0, 0)), (2, (-1, 0, 0)), (0, (0, 0, 0))):
+    term = ConstRef("coeff[%d]" % q) * pos(u(i + di, j + dj, k + dk), 0.0)
+    total = term if total is None else total + term
+v(i, j, k).assign(If(total > 0, total, -total))
+STENCIL = [v]
+"""
+LIMITER = HEAD + """
+lo = Func("min", 2); mag = Func("fabs", 1)
+dl = u(i, j, k) - u(i - 1, j, k); dr = u(i + 1, j, k) - u(i, j, k)
+far = u(i + 2, j - 1, k) * u(i - 2, j, k + 2) - u(i, j + 2, k - 2)
+v(i, j, k).assign(u(i, j, k) + 0.3 * If(dl * dr > 0, lo(mag(dl), mag(dr)), 0.0) * If(far >= 0, 1.0, -1.0))
+STENCIL = [v]
+"""
+
+
+def main():
+    dev = torch.device("cuda:0")
+    n = 512 // 8 + 2
+    grid, info = bl.init_grid((n, n, n), dev)
+    a, b = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(2))
+    a.dat.uniform_(-0.5, 0.5)
+    A, B = bl.Brick(info, a, 0), bl.Brick(info, b, 0)
+    from bricklib_amd.order import tiled
+    from bricklib_amd.brick import grid_to_device
+    ids = grid_to_device(tiled(grid.reshape(n, n, n)[1:-1, 1:-1, 1:-1]), dev)
+    coeff = [0.1 * (q - 3) for q in range(7)]
+    minmod = load_spec(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples", "minmod.py"))
+    cond = load_spec(COND)
+
+    def timed(name, fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print(f"{name:44s} {ms:7.3f} ms/sweep  {512 ** 3 / ms / 1e6:7.1f} GStencil/s  {bl.last_kernel()}", flush=True)
+
+    timed("cond.py tuned kernel (BRK_COND7)", lambda: bl.apply_stencil("cond", A, B, ids=ids, coeff=coeff + [0.0] * 122))
+    timed("cond-shaped script, expression path", lambda: bl.apply_expr(cond, A, B, ids=ids, constants={"coeff": coeff}))
+    lin = load_spec(COND.replace('pos(u(i + di, j + dj, k + dk), 0.0)', 'u(i + di, j + dj, k + dk)').replace("If(total > 0, total, -total)", "total"))
+    taps = lin.taps({"coeff": coeff})
+    timed("same 7 taps, linear tap path (k_taps)", lambda: bl.apply_taps(taps, A, B, ids=ids))
+    timed("same 7 taps, linear, expression path", lambda: bl.apply_expr(lin, A, B, ids=ids, constants={"coeff": coeff}))
+    timed("minmod.py (3 limited slopes), expression", lambda: bl.apply_expr(minmod, A, B, ids=ids, constants={"coeff": coeff}))
+    timed("radius-2 limiter, expression path", lambda: bl.apply_expr(load_spec(LIMITER), A, B, ids=ids))
+
+
+if __name__ == "__main__":
+    main()
