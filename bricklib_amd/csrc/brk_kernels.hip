@@ -713,6 +713,7 @@ extern "C" int brk_adjacency_release(const uint32_t *adj_dev) {
 // touched; the library stays usable (caches are rebuilt on demand, registrations are forgotten).
 extern "C" int brk_finalize(void) {
   HIP_TRY(hipDeviceSynchronize());
+  brk_jit_finalize();
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
   {
@@ -812,6 +813,7 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
       sp.off[t] = dk ? dk : (dj ? dj : di);
       sp.w[t] = weights_host[t];
     }
+    brk_note_kernel("k_star_taps<4>");
     hipLaunchKernelGGL((k_star_taps<4>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, sp);
     HIP_TRY(hipGetLastError());
     return BRK_OK;
@@ -825,6 +827,7 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
     tp.w[t] = weights_host[t];
   }
   const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
+  brk_note_kernel(tp.radius == 1 ? "k_taps<1,4>" : "k_taps<2,4>");
   if (tp.radius == 1) hipLaunchKernelGGL((k_taps<1, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);
   else hipLaunchKernelGGL((k_taps<2, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);
   HIP_TRY(hipGetLastError());
@@ -835,28 +838,13 @@ extern "C" int brk_stencil_apply_expr(const uint32_t *adj, const double *in, dou
                                       uint32_t n, const brk_expr_op *ops_host, uint32_t nops, uint32_t result_reg, brk_stream s) {
   if (!adj || !in || !out || in == out) return brk_fail(BRK_EINVAL, "bad device pointers");
   if (step < 512) return brk_fail(BRK_EINVAL, "step_elems %zu < 512", step);
-  if (!ops_host || nops == 0 || nops > (uint32_t)kMaxExprOps) return brk_fail(BRK_EINVAL, "1..%d ops expected (got %u)", kMaxExprOps, nops);
-  if (result_reg >= (uint32_t)kMaxExprRegs) return brk_fail(BRK_EINVAL, "result register %u (0..%d)", result_reg, kMaxExprRegs - 1);
-  if (n == 0) return BRK_OK;
-  // check the program: known codes, registers in range and WRITTEN before they are read (every lane starts with an undefined file)
+  if (n == 0) return ops_host && nops ? BRK_OK : brk_fail(BRK_EINVAL, "1..%d ops expected (got %u)", kMaxExprOps, nops);
+  static_assert(kMaxExprOps == BRK_EXPR_MAX_OPS && kMaxExprRegs == BRK_EXPR_MAX_REGS && (int)EX_SEL == (int)BRK_EX_SEL, "brk_internal.h / brk.h disagree with brick-device.h");
+  int radius = 1;
+  if (int rc = brk_expr_check(ops_host, nops, result_reg, &radius)) return rc;
   ExprProg pg;
   std::memset(&pg, 0, sizeof pg);
-  bool written[kMaxExprRegs] = {};
-  int maxabs = 0;
-  for (uint32_t t = 0; t < nops; ++t) {
-    const brk_expr_op &o = ops_host[t];
-    if (o.code >= (uint32_t)EX_NOPS) return brk_fail(BRK_EINVAL, "op %u: unknown code %u", t, o.code);
-    if (o.dst >= (uint32_t)kMaxExprRegs) return brk_fail(BRK_EINVAL, "op %u: destination register %u", t, o.dst);
-    const int nsrc = o.code == EX_TAP || o.code == EX_CONST ? 0 : (o.code == EX_NEG || o.code == EX_ABS || o.code == EX_SQRT ? 1 : (o.code == EX_SEL ? 3 : 2));
-    const uint32_t src[3] = {o.a, o.b, o.c};
-    for (int q = 0; q < nsrc; ++q)
-      if (src[q] >= (uint32_t)kMaxExprRegs || !written[src[q]]) return brk_fail(BRK_EINVAL, "op %u: source register %u is read before it is written", t, src[q]);
-    for (int a = 0; a < 3 && o.code == EX_TAP; ++a) maxabs = std::max(maxabs, o.offset[a] < 0 ? -o.offset[a] : o.offset[a]);
-    written[o.dst] = true;
-  }
-  if (!written[result_reg]) return brk_fail(BRK_EINVAL, "result register %u is never written", result_reg);
-  if (maxabs > 2) return brk_fail(BRK_EINVAL, "tap offset %d: expression stencils reach the 125-point cube (|offset| <= 2 per axis)", maxabs);
-  pg.n = (int)nops, pg.radius = maxabs > 1 ? 2 : 1, pg.result = (int)result_reg;
+  pg.n = (int)nops, pg.radius = radius, pg.result = (int)result_reg;
   for (uint32_t t = 0; t < nops; ++t) {
     const brk_expr_op &o = ops_host[t];
     ExprOp &d = pg.op[t];

@@ -56,25 +56,76 @@ def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coef
                                              _stream(stream)))
 
 
-def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None):
-    """A stencil script as an expression (brk_stencil_apply_expr): `spec` = bricklib_amd.spec.load_spec(...) of ANY script inside the
-    125-point cube -- Func("max" / "min" / "abs" / "sqrt"), comparisons, If, products of grid references included (what the
-    reference's generator accepts; stencils/cond.py is made of these).  constants: values of the script's ConstRef names.  The
-    general path; linear scripts are better served by apply_taps / the built-in stencils."""
+def _expr_table(spec, constants):
     from ._lib import ExprOp
     ops, result = spec.program(constants)
     tab = (ExprOp * len(ops))()
     for q, o in enumerate(ops):
         tab[q].code, tab[q].dst, tab[q].a, tab[q].b, tab[q].c, tab[q].imm = o["code"], o["dst"], o["a"], o["b"], o["c"], float(o["imm"])
         tab[q].offset[0], tab[q].offset[1], tab[q].offset[2] = o["offset"]
+    return tab, len(ops), result
+
+
+class CompiledExpr:
+    """A stencil script compiled at run time for the current device (brk_expr_compile: the script's operations as straight-line HIP
+    over the staged tile, through hiprtc; about a second, once per distinct program).  The counterpart of the reference's generate-then-
+    compile step (codegen/vecscatter) for a host that holds the script as data.  apply(bIn, bOut, ids= | brick_range=); .source is the
+    generated translation unit."""
+
+    def __init__(self, spec, constants=None):
+        import ctypes as C
+        tab, n, result = _expr_table(spec, constants)
+        self._h = C.c_void_p()
+        check(lib.brk_expr_compile(tab, n, result, C.byref(self._h)))
+
+    @property
+    def source(self):
+        return lib.brk_expr_kernel_source(self._h).decode()
+
+    def apply(self, bIn, bOut, ids=None, brick_range=None, stream=None):
+        adj = bIn.bInfo.adj
+        if ids is not None:
+            check(lib.brk_expr_apply(self._h, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids), 0, ids.numel(), _stream(stream)))
+        else:
+            b0, b1 = brick_range if brick_range is not None else (0, bIn.bInfo.nbricks)
+            check(lib.brk_expr_apply(self._h, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, None, int(b0), int(b1 - b0), _stream(stream)))
+
+    def release(self):
+        if self._h:
+            lib.brk_expr_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+def expr_source(spec, constants=None):
+    """the translation unit brk_expr_compile would compile for this script (no compiler, no device needed)"""
+    import ctypes as C
+    tab, n, result = _expr_table(spec, constants)
+    need = C.c_size_t()
+    check(lib.brk_expr_source(tab, n, result, None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    check(lib.brk_expr_source(tab, n, result, buf, need.value, None))
+    return buf.value.decode()
+
+
+def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None):
+    """A stencil script as an expression, INTERPRETED (brk_stencil_apply_expr): `spec` = bricklib_amd.spec.load_spec(...) of ANY script
+    inside the 125-point cube -- Func("max" / "min" / "abs" / "sqrt"), comparisons, If, products of grid references included (what the
+    reference's generator accepts; stencils/cond.py is made of these).  constants: values of the script's ConstRef names.  No compiler
+    involved and about 10x slower than CompiledExpr(spec, constants).apply(...), which runs the same operations as generated code;
+    linear scripts are better served by apply_taps / the built-in stencils."""
+    tab, n, result = _expr_table(spec, constants)
     adj = bIn.bInfo.adj
     if ids is not None:
-        check(lib.brk_stencil_apply_expr(_ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids), 0, ids.numel(), tab, len(ops), result,
-                                         _stream(stream)))
+        check(lib.brk_stencil_apply_expr(_ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids), 0, ids.numel(), tab, n, result, _stream(stream)))
     else:
         b0, b1 = brick_range if brick_range is not None else (0, bIn.bInfo.nbricks)
-        check(lib.brk_stencil_apply_expr(_ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, None, int(b0), int(b1 - b0), tab, len(ops), result,
-                                         _stream(stream)))
+        check(lib.brk_stencil_apply_expr(_ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, None, int(b0), int(b1 - b0), tab, n, result, _stream(stream)))
 
 
 def last_kernel():

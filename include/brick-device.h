@@ -8,9 +8,11 @@
 // function owns a static __shared__ tile per wave of the block.
 #ifndef BRICK_DEVICE_H
 #define BRICK_DEVICE_H
+#ifndef __HIPCC_RTC__ // run-time compilation (brk_expr_compile): hiprtc declares the runtime itself and has no standard headers
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#endif
 
 #include "brk.h"
 

@@ -23,8 +23,10 @@
 #ifndef BRK_H
 #define BRK_H
 
+#ifndef __HIPCC_RTC__ /* (run-time compilation of brick-device.h, brk_expr_compile: no standard headers there) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -63,7 +65,8 @@ const char *brk_last_error(void);
  * 1003: the ghost-zone exchange: brk_xplan_*, brk_exchange_*, brk_comm_*; 1004: brk_adjacency_register / _release;
  * 1005: brk_stencil_apply_{range,list,box}_ex with BRK_SWEEP_* flags; 1006: brk_comm_library, the development knob
  * brk_set_variant is no longer part of the ABI; 1007: brk_storage_alloc / brk_storage_free / brk_placement_probe;
- * 1008: brk_finalize, brk_last_kernel; 1009: brk_storage_alloc_ex; 1010: brk_stencil_apply_expr) */
+ * 1008: brk_finalize, brk_last_kernel; 1009: brk_storage_alloc_ex; 1010: brk_stencil_apply_expr;
+ * 1011: brk_expr_compile / brk_expr_apply / brk_expr_release / brk_expr_source / brk_expr_kernel_source) */
 int brk_abi_version(void);
 /* Orderly end of the library's use of the GPU before a process leaves main(): waits for everything enqueued on the current device
  * and releases, on the CALLING thread, what the library itself holds there (box id lists and their events, derived tables of
@@ -182,6 +185,23 @@ typedef struct {
 int brk_stencil_apply_expr(const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
                            const uint32_t *brick_ids_dev /* NULL: id range */, uint32_t first, uint32_t n,
                            const brk_expr_op *ops_host, uint32_t nops, uint32_t result_reg, brk_stream s);
+
+/* The same program COMPILED at run time (ABI 1011).  The reference turns a script into C++ before the compiler sees the driver
+ * (codegen/vecscatter); a host that holds the script as data gets that here: brk_expr_compile writes the operations out as
+ * straight-line HIP over the staged tile (the text tools/brkscatter emits for a brick(...) line; brk_expr_source returns it without
+ * compiling) and compiles it with hiprtc for the current device -- about a second, once per distinct program and device (a second
+ * compile of the same program returns the same kernel).  brk_expr_apply then runs at the speed of the generic tap path instead of the
+ * interpreter's.  Same operations, one fp64 rounding each (-ffp-contract=off): the same numbers as brk_stencil_apply_expr.
+ * BRK_ENODEV: libhiprtc could not be loaded, or there is no device.  brk_finalize unloads the modules; a kernel used after that is
+ * refused until its program is compiled again.  brk_expr_release when done (NULL is a no-op). */
+typedef struct brk_expr_kernel brk_expr_kernel;
+int brk_expr_compile(const brk_expr_op *ops_host, uint32_t nops, uint32_t result_reg, brk_expr_kernel **out);
+int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
+                   const uint32_t *brick_ids_dev /* or NULL */, uint32_t first, uint32_t n, brk_stream s);
+int brk_expr_release(brk_expr_kernel *k);
+/* the generated translation unit: of a program (buf may be NULL; *need = bytes incl. the terminator) / of a compiled kernel */
+int brk_expr_source(const brk_expr_op *ops_host, uint32_t nops, uint32_t result_reg, char *buf, size_t cap, size_t *need);
+const char *brk_expr_kernel_source(const brk_expr_kernel *k);
 /* Development builds of the library (make -C bricklib_amd/csrc DEV=1 or VARIANTS=1) additionally export the experiment knobs
  * used by tools/kbench (kernel variant selection, LDS padding, diagnostic modes), looked up with dlsym.  They are not declared
  * here and the default libbrk.so does not contain them: not part of this ABI. */

@@ -14,8 +14,12 @@ INC="-I$ROOT/include -I$ROOT/bricklib_amd/csrc -I/opt/rocm/include"
 HIPHOST="-x hip --cuda-host-only --offload-arch=gfx950 -nogpulib -std=c++17 -fPIC -Wno-unused-command-line-argument -Wno-unknown-cuda-version"
 mkdir -p "$OUT"
 cd "$OUT"
+# the two headers brk_jit.hip carries as text (bricklib_amd/csrc/Makefile: brk_jit_headers.inc)
+{ echo 'const char kJitDeviceHeader[] = R"BRKSRC('; cat "$ROOT/include/brick-device.h"; echo ')BRKSRC";'
+  echo 'const char kJitAbiHeader[] = R"BRKSRC('; cat "$ROOT/include/brk.h"; echo ')BRKSRC";'; } > brk_jit_headers.inc
+INC="-I$OUT $INC"
 pids=()
-for f in brk_kernels brk_star7 brk_starwg brk_cubedense brk_cube125q brk_place brk_exchange; do
+for f in brk_kernels brk_star7 brk_starwg brk_cubedense brk_cube125q brk_place brk_exchange brk_jit; do
   $CXX $HIPHOST -cuid=$f $SAN $INC -c "$ROOT/bricklib_amd/csrc/$f.hip" -o $f.o &
   pids+=($!)
 done
@@ -31,7 +35,7 @@ for p in "${pids[@]}"; do wait $p; done
 # the host pass of a translation unit with kernels refers to its device code object as __hip_fatbin_<id>: there is none
 nm brk_kernels.o brk_star7.o brk_starwg.o brk_cubedense.o brk_cube125q.o brk_place.o brk_exchange.o hipmock.o | awk '$1 == "U" && $2 ~ /^__hip_fatbin/ {print "const char " $2 "[16] = {0};"}' | sort -u > fatbins.c
 $CC -fPIC -c fatbins.c -o fatbins.o
-$CXX -shared $SAN -o libbrk.so brk_kernels.o brk_star7.o brk_starwg.o brk_cubedense.o brk_cube125q.o brk_place.o brk_exchange.o brk_host.o brk_xplan.o hipmock.o fatbins.o brick_oracle.o -ldl -lm
+$CXX -shared $SAN -o libbrk.so brk_kernels.o brk_star7.o brk_starwg.o brk_cubedense.o brk_cube125q.o brk_place.o brk_exchange.o brk_jit.o brk_host.o brk_xplan.o hipmock.o fatbins.o brick_oracle.o -ldl -lm
 $CXX -shared -fPIC -std=c++17 $SAN -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include "$ROOT/tests/hipmock/rcclmock.cpp" -o librccl.so.1
 LINK="-L$OUT -lbrk -Wl,-rpath,$OUT"
 $CXX $HIPHOST -cuid=strong_hip $SAN $INC -fopenmp -DBRK_NO_MPI -c "$ROOT/examples/strong_hip.cpp" -o strong_hip.o &

@@ -589,6 +589,18 @@ hipError_t hipGetDevice(int *d) {
   return hipSuccess;
 }
 hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+// run-time compiled modules (brk_expr_compile): there is nothing to load a code object on
+hipError_t hipModuleLoadData(hipModule_t *, const void *) { return g_last = hipErrorNotSupported; }
+hipError_t hipModuleGetFunction(hipFunction_t *, hipModule_t, const char *) { return g_last = hipErrorNotSupported; }
+hipError_t hipModuleUnload(hipModule_t) { return g_last = hipErrorNotSupported; }
+hipError_t hipModuleLaunchKernel(hipFunction_t, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, unsigned, hipStream_t, void **, void **) {
+  return g_last = hipErrorNotSupported;
+}
+hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600 *p, int) {
+  std::memset(p, 0, sizeof *p);
+  std::strcpy(p->gcnArchName, "gfx950");
+  return hipSuccess;
+}
 hipError_t hipGetDeviceCount(int *n) {
   *n = 1;
   return hipSuccess;

@@ -210,6 +210,14 @@ static int launches() {
     ops[6].code = BRK_EX_SUB, ops[6].dst = 2, ops[6].a = 0, ops[6].b = 1;
     REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 3, ops, 7, 2, nullptr) == BRK_OK);
     REQ(std::string(brk_last_kernel()) == "k_expr<2,4>");
+    // the same program as generated source (compiling it needs a device: tests/test_gpu_parity.py)
+    size_t need = 0;
+    REQ(brk_expr_source(ops, 7, 2, nullptr, 0, &need) == BRK_OK && need > 500);
+    std::vector<char> text(need);
+    REQ(brk_expr_source(ops, 7, 2, text.data(), text.size(), nullptr) == BRK_OK);
+    REQ(std::string(text.data()).find("c[brklib::tap_rel<2>(2, -1, 1)]") != std::string::npos && std::strlen(text.data()) + 1 == need);
+    REQ(brk_expr_source(ops, 7, 2, text.data(), 40, nullptr) == BRK_OK && std::strlen(text.data()) == 39); // truncated, terminated
+    REQ(brk_expr_release(nullptr) == BRK_OK);
     REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 0, 3, ops, 7, 3, nullptr) != BRK_OK); // register 3 is never written
     ops[4].b = 9;
     REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 0, 3, ops, 7, 2, nullptr) != BRK_OK); // read before written

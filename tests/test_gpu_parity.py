@@ -988,6 +988,12 @@ def test_stencil_given_as_expression(oracle, dev, case):
     real = lst[lst != LIST_SKIP]
     oracle.brick_expr(spec, info.adj_host, hin, want, 512, real, consts)
     agree(so.dat.cpu().numpy(), want)
+    # the same program compiled at run time (brk_expr_compile): same operations, one rounding each -> the interpreter's numbers
+    ck = bl.CompiledExpr(spec, consts)
+    sc = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    ck.apply(bl.Brick(info, st, 0), bl.Brick(info, sc, 0), ids=grid_to_device(lst, dev))
+    assert bl.last_kernel() == ("k_expr_jit<2>" if spec.radius == 2 else "k_expr_jit<1>")
+    assert torch.equal(sc.dat, so.dat) and "brick_apply_fn" in ck.source
     if case == "cond":
         sb = bl.BrickStorage.allocate(info.nbricks, 512, dev)
         bl.apply_stencil("cond", bl.Brick(info, st, 0), bl.Brick(info, sb, 0), ids=grid_to_device(lst, dev), coeff=coeff)
@@ -1003,6 +1009,46 @@ def test_stencil_given_as_expression(oracle, dev, case):
     want2 = np.zeros_like(hin2)
     oracle.brick_expr(spec, d.adj, hin2, want2, 512, np.arange(1, d.sep_pos[2], dtype=np.uint32), consts)
     agree(B.dat.cpu().numpy(), want2)
+    C = dinfo.allocate(512, dev)
+    ck.apply(bl.Brick(dinfo, A, 0), bl.Brick(dinfo, C, 0), brick_range=(1, d.sep_pos[2]))
+    assert torch.equal(C.dat, B.dat)
+    ck.release()
+
+
+def test_compiled_expression_lifecycle(dev):
+    """brk_expr_compile: one kernel per distinct program (a second compile returns the first), other constants = another kernel,
+    brk_finalize unloads the modules (a kernel used afterwards is refused, compiling the program again revives it), release twice is
+    reported"""
+    import ctypes as C
+    from bricklib_amd._lib import BrkError, lib
+    from bricklib_amd.spec import load_spec
+    spec = load_spec(EXPR_SCRIPTS["limiter"])
+    grid, info = bl.init_grid((4, 4, 4), dev)
+    st, s1, s2 = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(3))
+    st.dat.uniform_(-0.5, 0.5)
+    a = bl.CompiledExpr(spec, {"cfl": 0.3})
+    b = bl.CompiledExpr(spec, {"cfl": 0.3})
+    c = bl.CompiledExpr(spec, {"cfl": 0.25})
+    assert a._h.value == b._h.value and c._h.value != a._h.value
+    a.apply(bl.Brick(info, st, 0), bl.Brick(info, s1, 0))
+    c.apply(bl.Brick(info, st, 0), bl.Brick(info, s2, 0))
+    assert not torch.equal(s1.dat, s2.dat)
+    bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, s2, 0), constants={"cfl": 0.3})
+    assert torch.equal(s1.dat, s2.dat)
+    with pytest.raises(BrkError):
+        a.apply(bl.Brick(info, st, 0), bl.Brick(info, st, 0))          # in == out
+    bl.finalize()
+    with pytest.raises(BrkError, match="unloaded"):
+        a.apply(bl.Brick(info, st, 0), bl.Brick(info, s1, 0))
+    again = bl.CompiledExpr(spec, {"cfl": 0.3})
+    assert again._h.value == a._h.value
+    s2.dat.zero_()
+    a.apply(bl.Brick(info, st, 0), bl.Brick(info, s2, 0))
+    assert torch.equal(s1.dat, s2.dat)
+    handle = c._h.value
+    for k in (a, b, c, again):
+        k.release()
+    assert lib.brk_expr_release(C.c_void_p(handle)) != 0               # gone already
 
 
 def test_expression_argument_checks(dev):

@@ -199,3 +199,22 @@ def test_oracle_tap_evaluation_agrees_with_pinned_stencils(oracle):
         oracle.brick_stencil(sid, adj, hin, a, 512, ids=ids, coeff=c)
         oracle.brick_taps(adj, hin, b, 512, ids, taps)
         assert np.abs(a - b).max() <= 1e-14 and np.abs(b).max() > 0
+
+
+def test_expression_source_generation_and_compilation_without_a_device():
+    """brk_expr_source: the translation unit of a program (one statement per operation, constants as exact hexadecimal literals,
+    taps as tile offsets).  brk_expr_compile gets as far as a code object for gfx950 here -- hiprtc needs no GPU -- and then reports
+    that there is no device to load it on (BRK_ENODEV); with a device: tests/test_gpu_parity.py."""
+    import torch
+    from bricklib_amd._lib import BrkError
+    from bricklib_amd.stencils import CompiledExpr, expr_source
+    s = load_spec(PRELUDE + NONLINEAR[3])
+    text = expr_source(s, {"lim": 0.75})
+    ops, result = s.program({"lim": 0.75})
+    assert text.count(";\n    r") + 1 >= len(ops) and f"return r{result};" in text
+    assert "brklib::brick_apply_fn<2, 4>(" in text and "c[brklib::tap_rel<2>(0, -2, 0)]" in text and "0x1.8p-1" in text and "__builtin_sqrt(" in text
+    assert expr_source(s, {"lim": 0.75}) == text and expr_source(s, {"lim": 0.5}) != text
+    if torch.cuda.is_available():
+        return
+    with pytest.raises(BrkError, match="compiled for gfx950 .* no device|libhiprtc"):
+        CompiledExpr(s, {"lim": 0.75})

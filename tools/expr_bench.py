@@ -62,13 +62,25 @@ def main():
         print(f"{name:44s} {ms:7.3f} ms/sweep  {512 ** 3 / ms / 1e6:7.1f} GStencil/s  {bl.last_kernel()}", flush=True)
 
     timed("cond.py tuned kernel (BRK_COND7)", lambda: bl.apply_stencil("cond", A, B, ids=ids, coeff=coeff + [0.0] * 122))
-    timed("cond-shaped script, expression path", lambda: bl.apply_expr(cond, A, B, ids=ids, constants={"coeff": coeff}))
+    timed("cond-shaped script, interpreted", lambda: bl.apply_expr(cond, A, B, ids=ids, constants={"coeff": coeff}))
+    import time
+    t0 = time.time()
+    ck = bl.CompiledExpr(cond, {"coeff": coeff})
+    print(f"  (brk_expr_compile: {time.time() - t0:.2f} s)")
+    timed("cond-shaped script, compiled at run time", lambda: ck.apply(A, B, ids=ids))
     lin = load_spec(COND.replace('pos(u(i + di, j + dj, k + dk), 0.0)', 'u(i + di, j + dj, k + dk)').replace("If(total > 0, total, -total)", "total"))
     taps = lin.taps({"coeff": coeff})
     timed("same 7 taps, linear tap path (k_taps)", lambda: bl.apply_taps(taps, A, B, ids=ids))
-    timed("same 7 taps, linear, expression path", lambda: bl.apply_expr(lin, A, B, ids=ids, constants={"coeff": coeff}))
-    timed("minmod.py (3 limited slopes), expression", lambda: bl.apply_expr(minmod, A, B, ids=ids, constants={"coeff": coeff}))
-    timed("radius-2 limiter, expression path", lambda: bl.apply_expr(load_spec(LIMITER), A, B, ids=ids))
+    timed("same 7 taps, linear, interpreted", lambda: bl.apply_expr(lin, A, B, ids=ids, constants={"coeff": coeff}))
+    cl = bl.CompiledExpr(lin, {"coeff": coeff})
+    timed("same 7 taps, linear, compiled", lambda: cl.apply(A, B, ids=ids))
+    timed("minmod.py (3 limited slopes), interpreted", lambda: bl.apply_expr(minmod, A, B, ids=ids, constants={"coeff": coeff}))
+    cm = bl.CompiledExpr(minmod, {"coeff": coeff})
+    timed("minmod.py (3 limited slopes), compiled", lambda: cm.apply(A, B, ids=ids))
+    lim = load_spec(LIMITER)
+    timed("radius-2 limiter, interpreted", lambda: bl.apply_expr(lim, A, B, ids=ids))
+    c2 = bl.CompiledExpr(lim)
+    timed("radius-2 limiter, compiled", lambda: c2.apply(A, B, ids=ids))
 
 
 if __name__ == "__main__":
