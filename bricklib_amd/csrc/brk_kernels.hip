@@ -87,6 +87,21 @@ __global__ __launch_bounds__(64 * WPW) void k_taps(const uint32_t *__restrict__ 
   taps_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, b, tp, threadIdx.x & 63);
 }
 
+// cube-shaped table of radius 3 or 4 (up to 729 taps, table in device memory): CubeWaves<R>::WAVES waves per workgroup
+template <int R, int WPW>
+__global__ __launch_bounds__(64 * WPW) void k_taps_far(const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                                       double *__restrict__ out, size_t step, const uint32_t *__restrict__ ids,
+                                                       uint32_t first, uint32_t n, TapsFar tp) {
+  __shared__ double lds[WPW * CubeTile<R>::ELEMS];
+  const uint32_t per_xcd = gridDim.x >> 3;
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t slot = wg * WPW + (threadIdx.x >> 6);
+  if (slot >= n) return;
+  const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
+  if (b == BRK_LIST_SKIP) return;
+  taps_far_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, b, tp, threadIdx.x & 63);
+}
+
 // non-linear stencil given as a register program (brk_stencil_apply_expr): one wave per brick, generic staging
 template <int R, int WPW>
 __global__ __launch_bounds__(64 * WPW) void k_expr(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
@@ -711,6 +726,54 @@ extern "C" int brk_adjacency_release(const uint32_t *adj_dev) {
 // with their events, retired lists, the derived tables of adjacency tables that are still registered -- is released by the
 // CALLING thread, not by static destructors racing the HIP runtime's own exit handlers.  Caller memory is not
 // touched; the library stays usable (caches are rebuilt on demand, registrations are forgotten).
+// Tap tables too large for a kernel argument (cube-shaped, radius 3 and 4): kept on the device per (device, content); the same table
+// arrives again with every sweep of a time loop.  Uploaded once, synchronously; at most kMaxFarTables live (the oldest goes, after the
+// device has drained).  Layout: n ints (tap_rel), padded to 8 bytes, then n doubles.
+struct FarTable {
+  int device = 0, n = 0, radius = 0;
+  std::vector<int32_t> offsets;
+  std::vector<double> weights;
+  char *dev = nullptr;
+};
+static std::mutex g_far_mutex;
+static std::vector<FarTable> g_far;
+constexpr size_t kMaxFarTables = 32;
+
+static int far_table_locked(int radius, uint32_t ntaps, const int32_t *offsets, const double *weights, TapsFar *out) {
+  int device = 0;
+  HIP_TRY(hipGetDevice(&device));
+  for (FarTable &f : g_far)
+    if (f.device == device && f.n == (int)ntaps && f.radius == radius && std::memcmp(f.offsets.data(), offsets, ntaps * 12) == 0 &&
+        std::memcmp(f.weights.data(), weights, ntaps * 8) == 0) {
+      out->n = f.n, out->rel = reinterpret_cast<const int *>(f.dev), out->w = reinterpret_cast<const double *>(f.dev + (((size_t)f.n * 4 + 7) & ~(size_t)7));
+      return BRK_OK;
+    }
+  if (g_far.size() >= kMaxFarTables) {
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(g_far.front().dev);
+    g_far.erase(g_far.begin());
+  }
+  FarTable f;
+  f.device = device, f.n = (int)ntaps, f.radius = radius;
+  f.offsets.assign(offsets, offsets + 3 * ntaps);
+  f.weights.assign(weights, weights + ntaps);
+  const size_t woff = ((size_t)ntaps * 4 + 7) & ~(size_t)7;
+  std::vector<char> host(woff + (size_t)ntaps * 8, 0);
+  for (uint32_t t = 0; t < ntaps; ++t) {
+    const int di = offsets[3 * t], dj = offsets[3 * t + 1], dk = offsets[3 * t + 2];
+    reinterpret_cast<int *>(host.data())[t] = radius == 3 ? tap_rel<3>(di, dj, dk) : tap_rel<4>(di, dj, dk);
+  }
+  std::memcpy(host.data() + woff, weights, (size_t)ntaps * 8);
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&f.dev), host.size()));
+  if (hipError_t e = hipMemcpy(f.dev, host.data(), host.size(), hipMemcpyHostToDevice); e != hipSuccess) {
+    (void)hipFree(f.dev);
+    return brk_fail(BRK_EHIP, "tap table upload: %s", hipGetErrorString(e));
+  }
+  out->n = f.n, out->rel = reinterpret_cast<const int *>(f.dev), out->w = reinterpret_cast<const double *>(f.dev + woff);
+  g_far.push_back(std::move(f));
+  return BRK_OK;
+}
+
 extern "C" int brk_finalize(void) {
   HIP_TRY(hipDeviceSynchronize());
   brk_jit_finalize();
@@ -741,6 +804,11 @@ extern "C" int brk_finalize(void) {
     std::lock_guard<std::mutex> lock(g_adj_mutex);
     for (AdjEntry &e : g_adj) free_entry(e);
     g_adj.clear();
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_far_mutex);
+    for (FarTable &f : g_far) (void)hipFree(f.dev);
+    g_far.clear();
   }
   HIP_TRY(hipDeviceSynchronize());
   return BRK_OK;
@@ -783,11 +851,12 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
                                       const double *weights_host, brk_stream s) {
   if (!adj || !in || !out || in == out) return brk_fail(BRK_EINVAL, "bad device pointers");
   if (step < 512) return brk_fail(BRK_EINVAL, "step_elems %zu < 512", step);
-  if (ntaps == 0 || ntaps > (uint32_t)kMaxTaps || !offsets_host || !weights_host)
-    return brk_fail(BRK_EINVAL, "1..%d taps with host offset and weight arrays expected (got %u)", kMaxTaps, ntaps);
+  if (ntaps == 0 || ntaps > (uint32_t)kMaxFarTaps || !offsets_host || !weights_host)
+    return brk_fail(BRK_EINVAL, "1..%d taps with host offset and weight arrays expected (got %u)", kMaxFarTaps, ntaps);
   if (n == 0) return BRK_OK;
-  // shape of the table: cube-shaped taps inside the 125-point cube (|offset| <= 2 on every axis) run on the staged (8+2R)^3 tile;
-  // star-shaped taps (one axis per tap) reach radius 4 on the star staging; anything else has no path
+  // shape of the table: taps inside the 125-point cube (|offset| <= 2 on every axis) run on the staged (8+2R)^3 tile with the table as a
+  // kernel argument; star-shaped taps (one axis per tap) reach radius 4 on the star staging; cube-shaped taps of radius 3 and 4 (up to
+  // 9^3) run on the larger tiles with the table in device memory
   int maxabs = 0;
   bool star = true;
   for (uint32_t t = 0; t < ntaps; ++t) {
@@ -800,10 +869,24 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
     star = star && nonzero <= 1;
   }
   hipStream_t st = static_cast<hipStream_t>(s);
+  if (maxabs > 4) return brk_fail(BRK_EINVAL, "taps reach offset %d: tables are limited to [-4,4] per axis", maxabs);
+  if (maxabs > 2 && (!star || ntaps > (uint32_t)kMaxStarTaps)) {
+    TapsFar tf;
+    {
+      std::lock_guard<std::mutex> lock(g_far_mutex);
+      if (int rc = far_table_locked(maxabs, ntaps, offsets_host, weights_host, &tf)) return rc;
+    }
+    if (maxabs == 3) {
+      brk_note_kernel("k_taps_far<3,2>");
+      hipLaunchKernelGGL((k_taps_far<3, 2>), dim3((((n + 1) / 2 + 7) / 8) * 8), dim3(128), 0, st, adj, in, out, step, ids, first, n, tf);
+    } else {
+      brk_note_kernel("k_taps_far<4,1>");
+      hipLaunchKernelGGL((k_taps_far<4, 1>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, tf);
+    }
+    HIP_TRY(hipGetLastError());
+    return BRK_OK;
+  }
   if (maxabs > 2) {
-    if (!star || maxabs > 4)
-      return brk_fail(BRK_EINVAL, "taps reach offset %d: cube-shaped tables are limited to [-2,2] per axis, star-shaped ones (one axis per tap) to [-4,4]", maxabs);
-    if (ntaps > (uint32_t)kMaxStarTaps) return brk_fail(BRK_EINVAL, "%u star taps exceed %d", ntaps, kMaxStarTaps);
     StarTaps sp;
     std::memset(&sp, 0, sizeof sp);
     sp.n = (int)ntaps;
@@ -818,6 +901,7 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
     HIP_TRY(hipGetLastError());
     return BRK_OK;
   }
+  if (ntaps > (uint32_t)kMaxTaps) return brk_fail(BRK_EINVAL, "%u taps inside the 125-point cube (at most %d: one per point)", ntaps, kMaxTaps);
   Taps tp;
   tp.n = (int)ntaps;
   tp.radius = maxabs > 1 ? 2 : 1;
@@ -849,14 +933,18 @@ extern "C" int brk_stencil_apply_expr(const uint32_t *adj, const double *in, dou
     const brk_expr_op &o = ops_host[t];
     ExprOp &d = pg.op[t];
     d.code = (uint8_t)o.code, d.dst = (uint8_t)o.dst, d.a = (uint8_t)o.a, d.b = (uint8_t)o.b, d.c = (uint8_t)o.c;
-    d.rel = o.code == EX_TAP ? (pg.radius == 1 ? tap_rel<1>(o.offset[0], o.offset[1], o.offset[2]) : tap_rel<2>(o.offset[0], o.offset[1], o.offset[2])) : 0;
+    const int di = o.offset[0], dj = o.offset[1], dk = o.offset[2];
+    d.rel = o.code != EX_TAP ? 0 : (pg.radius == 1 ? tap_rel<1>(di, dj, dk) : (pg.radius == 2 ? tap_rel<2>(di, dj, dk) : (pg.radius == 3 ? tap_rel<3>(di, dj, dk) : tap_rel<4>(di, dj, dk))));
     d.imm = o.imm;
   }
   hipStream_t st = static_cast<hipStream_t>(s);
   const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
-  brk_note_kernel(pg.radius == 1 ? "k_expr<1,4>" : "k_expr<2,4>");
+  static const char *const names[] = {"k_expr<1,4>", "k_expr<2,4>", "k_expr<3,2>", "k_expr<4,1>"};
+  brk_note_kernel(names[pg.radius - 1]);
   if (pg.radius == 1) hipLaunchKernelGGL((k_expr<1, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, pg);
-  else hipLaunchKernelGGL((k_expr<2, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, pg);
+  else if (pg.radius == 2) hipLaunchKernelGGL((k_expr<2, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, pg);
+  else if (pg.radius == 3) hipLaunchKernelGGL((k_expr<3, 2>), dim3((((n + 1) / 2 + 7) / 8) * 8), dim3(128), 0, st, adj, in, out, step, ids, first, n, pg);
+  else hipLaunchKernelGGL((k_expr<4, 1>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, pg);
   HIP_TRY(hipGetLastError());
   return BRK_OK;
 }

@@ -8,10 +8,10 @@ and its code generator turns the expression into vector code (codegen/vecscatter
 only *read*: it is executed against the recording stand-ins below for `st.expr` / `st.grid` / `st.func`, which keep the
 expression as a tree.  From the tree:
   * a LINEAR script reduces to a list of taps (offset, coefficient expression): one of the built-in stencils -> its tuned kernel;
-    anything else inside the 125-point cube, or star-shaped up to radius 4 -> brk_stencil_apply_taps / brklib::brick_apply_taps;
+    anything else up to radius 4 (cube- or star-shaped) -> brk_stencil_apply_taps / brklib::brick_apply_taps;
   * a NON-LINEAR script (Func("max" | "min" | "abs" | "fabs" | "sqrt" ...), comparisons, If, products of grid references: what
     stencils/cond.py is made of; round 5) becomes a small register program (Spec.program) for brk_stencil_apply_expr /
-    brklib::brick_apply_expr -- the general path, inside the 125-point cube.
+    brklib::brick_apply_fn, or compiled at run time (brk_expr_compile) -- the general path, up to radius 4.
 This module is written from the script syntax alone; it shares no code with the reference's `st` package."""
 import re
 import sys
@@ -254,8 +254,8 @@ class Spec:
         {code, dst, a, b, c, offset, imm}; at most 16 registers live at a time (a sub-expression used several times, like `calc` in
         cond.py's If(calc > 0, calc, -calc), is computed once and kept).  constants: as for taps(); as_c: `imm` of a ConstRef stays its
         C text (what tools/brkscatter writes into a driver, where `coeff[3]` is an lvalue of the kernel)."""
-        if self.radius > 2:
-            raise ValueError(f"radius {self.radius}: expression stencils reach the 125-point cube (|offset| <= 2 per axis)")
+        if self.radius > 4:
+            raise ValueError(f"radius {self.radius}: stencils given as data reach |offset| <= 4 per axis")
         value = _resolver(constants)
         uses = {}
 

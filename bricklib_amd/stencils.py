@@ -115,7 +115,7 @@ def expr_source(spec, constants=None):
 
 def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None):
     """A stencil script as an expression, INTERPRETED (brk_stencil_apply_expr): `spec` = bricklib_amd.spec.load_spec(...) of ANY script
-    inside the 125-point cube -- Func("max" / "min" / "abs" / "sqrt"), comparisons, If, products of grid references included (what the
+    up to radius 4 -- Func("max" / "min" / "abs" / "sqrt"), comparisons, If, products of grid references included (what the
     reference's generator accepts; stencils/cond.py is made of these).  constants: values of the script's ConstRef names.  No compiler
     involved and about 10x slower than CompiledExpr(spec, constants).apply(...), which runs the same operations as generated code;
     linear scripts are better served by apply_taps / the built-in stencils."""
@@ -151,7 +151,7 @@ class Zigzag:
 
 def apply_taps(taps, bIn, bOut, ids=None, brick_range=None, stream=None):
     """A linear stencil given as data (brk_stencil_apply_taps): taps = [((di, dj, dk), weight), ...], applied in list order -- any
-    table with offsets in [-2, 2], or a star-shaped one (one axis per tap) with offsets in [-4, 4]; e.g. the output of
+    table with offsets in [-4, 4] (up to 729 taps; inside the 125-point cube and star-shaped tables have lighter kernels); e.g. the output of
     bricklib_amd.spec.load_spec(...).taps(constants)."""
     off = np.ascontiguousarray([list(o) for o, _ in taps], dtype=np.int32).reshape(-1)
     w = np.ascontiguousarray([float(x) for _, x in taps], dtype=np.float64)

@@ -88,6 +88,15 @@ __global__ void minmod_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Br
   brick("minmod.py", VSVEC, (BDIM), (VFOLD), b);
 }
 
+// ... and one beyond the 125-point cube: examples/blur343.py, all 343 points of the radius-3 cube (offsets and weights in LDS)
+__global__ void blur343_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Brick3D bOut, bElem *coeff) {
+  long tk = GB + hipBlockIdx_z;
+  long tj = GB + hipBlockIdx_y;
+  long ti = GB + hipBlockIdx_x;
+  unsigned b = grid[tk][tj][ti];
+  brick("blur343.py", VSVEC, (BDIM), (VFOLD), b);
+}
+
 static int run() {
   bElem *coeff = (bElem *)malloc(COEFF_SIZE * sizeof(bElem));
   {
@@ -243,6 +252,24 @@ static int run() {
     hipLaunchKernelGGL(minmod_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
     gpuCheck(hipDeviceSynchronize());
     check("brick() minmod kernel (non-linear script, generated straight-line code)");
+  }
+  // (7) a user-written radius-3 CUBE (blur343.py): 343 taps, tap table in LDS
+  {
+#pragma omp parallel for collapse(2)
+    for (long k = PADDING + GZ; k < PADDING + GZ + N; ++k)
+      for (long j = PADDING + GZ; j < PADDING + GZ + N; ++j)
+        for (long i = PADDING + GZ; i < PADDING + GZ + N; ++i) {
+          bElem acc = 0;
+          for (int dk = -3; dk <= 3; ++dk)
+            for (int dj = -3; dj <= 3; ++dj)
+              for (int di = -3; di <= 3; ++di) acc += coeff[std::abs(di) + std::abs(dj) + std::abs(dk)] * arr_in[k + dk][j + dj][i + di];
+          arr_out[k][j][i] = acc;
+        }
+    Brick3D dIn(binfo_dev, bstorage_dev, 0), dOut(binfo_dev, bstorage_dev, bsize);
+    dim3 block(NB, NB, NB), thread(64);
+    hipLaunchKernelGGL(blur343_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
+    gpuCheck(hipDeviceSynchronize());
+    check("brick() blur343 kernel (radius-3 cube script, 343 taps)");
   }
   return 0;
 }

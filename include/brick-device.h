@@ -186,9 +186,10 @@ __device__ __forceinline__ void star_brick(double *tile, const uint32_t *__restr
 template <int R>
 struct CubeTile {
   static constexpr int T = 8 + 2 * R;
-  static constexpr int P = R == 1 ? 10 : 12; // i pitch in doubles: some lanes of a half-wave collide 2-way (PMC: half of the LDS cycles
-                                             // of the 125-pt kernel are conflict cycles); pitch 24 is conflict-free but halves occupancy
-                                             // and measured slower (1.37 vs 1.07 ms)
+  static constexpr int P = R == 1 ? 10 : (R == 2 ? 12 : T); // i pitch in doubles: some lanes of a half-wave collide 2-way (PMC: half of the
+                                             // LDS cycles of the 125-pt kernel are conflict cycles); pitch 24 is conflict-free but halves
+                                             // occupancy and measured slower (1.37 vs 1.07 ms).  R = 3, 4 (22 / 32 KiB per wave): stencils
+                                             // given as data beyond the 125-point cube, the general path only
   static constexpr int ELEMS = T * T * P;
   __host__ __device__ static constexpr int at(int kk, int jj, int ii) { return (kk * T + jj) * P + ii; }
   static constexpr int NEXTRA = T * T * T - 512 - 6 * 64 * R;
@@ -224,11 +225,16 @@ constexpr ExtraTable<R> make_extra_table() {
 
 static __device__ const ExtraTable<1> g_extra1 = make_extra_table<1>();
 static __device__ const ExtraTable<2> g_extra2 = make_extra_table<2>();
+static __device__ const ExtraTable<3> g_extra3 = make_extra_table<3>();
+static __device__ const ExtraTable<4> g_extra4 = make_extra_table<4>();
 
 template <int R>
 __device__ __forceinline__ const uint32_t *extra_table() {
+  static_assert(R >= 1 && R <= 4, "halo radius 1..4");
   if (R == 1) return g_extra1.e;
-  return g_extra2.e;
+  if (R == 2) return g_extra2.e;
+  if (R == 3) return g_extra3.e;
+  return g_extra4.e;
 }
 
 enum CubeKind { kCube27, kCube125, kDiamond25 };
@@ -708,7 +714,8 @@ __device__ __forceinline__ void cube_brick(double *tile, const uint32_t *__restr
 // rel[t] = offset of tap t relative to the centre cell inside a CubeTile<R>: (dk * T + dj) * P + di.
 // One LDS read + one FMA per tap and output plane: the general path, slower than the hand-scheduled kernels above.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kMaxTaps = 125;
+constexpr int kMaxTaps = 125;     // table as a kernel argument (radius <= 2)
+constexpr int kMaxFarTaps = 729;  // table in device memory (radius 3, 4)
 struct Taps {
   int n, radius;
   int rel[kMaxTaps];
@@ -740,8 +747,43 @@ __device__ __forceinline__ void taps_brick(double *tile, const uint32_t *__restr
   for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
 }
 
+// Cube-shaped tables of radius 3 and 4 (up to 9^3 = 729 taps): the table lives in device memory, read through scalar loads.
+struct TapsFar {
+  int n;
+  const int *rel;    // tap_rel<R>
+  const double *w;
+};
+
+template <int R>
+__device__ __forceinline__ void taps_far_brick(double *tile, const uint32_t *__restrict__ adj, const double *__restrict__ in,
+                                               double *__restrict__ out, size_t step, uint32_t b, const TapsFar &tp, int lane) {
+  using TL = CubeTile<R>;
+  const int hi = lane >> 3, lo = lane & 7;
+  cube_stage<R>(tile, adj, in, step, b, lane);
+  const double *c = tile + TL::at(R, hi + R, lo + R);
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+#pragma unroll 1
+  for (int t = 0; t < tp.n; ++t) {
+    const int o = __builtin_amdgcn_readfirstlane(tp.rel[t]);
+    const double w = tp.w[t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += w * c[k * TL::T * TL::P + o];
+  }
+  double *dst = out + (size_t)b * step;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
+}
+
+// waves of one workgroup that fit the 64 KiB of static LDS with a CubeTile<R> each
+template <int R>
+struct CubeWaves {
+  static constexpr int WAVES = R <= 2 ? 4 : (R == 3 ? 2 : 1); // (not `N`: the reference's drivers #define N)
+};
+
 // user-kernel entry point (what tools/brkscatter emits for a stencil script that is not one of the built-in ones)
-template <int R, int MAXW = 4>
+template <int R, int MAXW = CubeWaves<R>::WAVES>
 __device__ __forceinline__ void brick_apply_taps(const uint32_t *adj, const double *in, double *out, size_t step, uint32_t b,
                                                  const Taps &tp) {
   __shared__ double lds[MAXW * CubeTile<R>::ELEMS];
@@ -750,7 +792,7 @@ __device__ __forceinline__ void brick_apply_taps(const uint32_t *adj, const doub
 }
 
 // The same with the tap table known at compile time (NTAPS taps; drivers of the reference #define N, offsets `rel`, weights `w` in registers): fully unrolled.
-template <int R, int NTAPS, int MAXW = 4>
+template <int R, int NTAPS, int MAXW = CubeWaves<R>::WAVES>
 __device__ __forceinline__ void brick_apply_taps_static(const uint32_t *adj, const double *in, double *out, size_t step,
                                                         uint32_t b, const int (&rel)[NTAPS], const double (&w)[NTAPS]) {
   using TL = CubeTile<R>;
@@ -767,6 +809,43 @@ __device__ __forceinline__ void brick_apply_taps_static(const uint32_t *adj, con
   for (int t = 0; t < NTAPS; ++t) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] += w[t] * c[k * TL::T * TL::P + rel[t]];
+  }
+  double *dst = out + (size_t)b * step;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], acc[k]);
+}
+
+// Hundreds of taps known at compile time (a cube-shaped script of radius 3 or 4: up to 9^3): a weight table in registers would
+// spill, so lane 0 of each wave writes offsets and weights to LDS behind the tile -- every weight is evaluated and stored at once --
+// and the tap loop stays rolled: one broadcast LDS read of (offset, weight) per tap, then the 8 plane reads + FMAs.
+template <int R, int NTAPS, int MAXW = CubeWaves<R>::WAVES>
+__device__ __forceinline__ void brick_apply_taps_table(const uint32_t *adj, const double *in, double *out, size_t step,
+                                                       uint32_t b, const int (&rel)[NTAPS], const double (&w)[NTAPS]) {
+  using TL = CubeTile<R>;
+  static_assert(MAXW * (TL::ELEMS + NTAPS + (NTAPS + 1) / 2) * 8 <= 65536, "tile + tap table exceed the static LDS of a workgroup");
+  __shared__ double lds[MAXW * TL::ELEMS];
+  __shared__ double wtab[MAXW * NTAPS];
+  __shared__ int rtab[MAXW * NTAPS];
+  const int lane = threadIdx.x & 63, hi = lane >> 3, lo = lane & 7, wave = threadIdx.x >> 6;
+  double *tile = lds + wave * TL::ELEMS;
+  double *wt = wtab + wave * NTAPS;
+  int *rt = rtab + wave * NTAPS;
+  b = __builtin_amdgcn_readfirstlane(b);
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) wt[t] = w[t], rt[t] = rel[t];
+  }
+  cube_stage<R>(tile, adj, in, step, b, lane); // ends with the wave's LDS fence: the table is visible too
+  const double *c = tile + TL::at(R, hi + R, lo + R);
+  double acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+#pragma unroll 1
+  for (int t = 0; t < NTAPS; ++t) {
+    const int o = __builtin_amdgcn_readfirstlane(rt[t]);
+    const double wv = wt[t];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += wv * c[k * TL::T * TL::P + o];
   }
   double *dst = out + (size_t)b * step;
 #pragma unroll
@@ -837,7 +916,7 @@ __device__ __forceinline__ void expr_brick(double *tile, const uint32_t *__restr
 }
 
 // user-kernel entry point (what tools/brkscatter emits for a non-linear stencil script)
-template <int R, int MAXW = 4>
+template <int R, int MAXW = CubeWaves<R>::WAVES>
 __device__ __forceinline__ void brick_apply_expr(const uint32_t *adj, const double *in, double *out, size_t step, uint32_t b, const ExprProg &pg) {
   __shared__ double lds[MAXW * CubeTile<R>::ELEMS];
   expr_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, __builtin_amdgcn_readfirstlane(b), pg, threadIdx.x & 63);
@@ -846,7 +925,7 @@ __device__ __forceinline__ void brick_apply_expr(const uint32_t *adj, const doub
 // The same with the expression known at compile time (what tools/brkscatter emits for a non-linear stencil script: the script's operations
 // written out as straight-line C++ in a lambda).  f(c): the value of one cell, c = the cell's own position in the staged tile, a
 // grid reference in[p + (di, dj, dk)] is c[tap_rel<R>(di, dj, dk)].
-template <int R, int MAXW = 4, class F>
+template <int R, int MAXW = CubeWaves<R>::WAVES, class F>
 __device__ __forceinline__ void brick_apply_fn(const uint32_t *adj, const double *in, double *out, size_t step, uint32_t b, F f) {
   using TL = CubeTile<R>;
   __shared__ double lds[MAXW * TL::ELEMS];

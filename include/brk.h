@@ -161,10 +161,12 @@ int brk_adjacency_release(const uint32_t *adj_dev);
 /* A linear stencil given as data -- the capability of the reference's code generator for scripts that are not one of the
  * built-in ones (codegen/vecscatter evaluating stencils/<name>.py; bricklib_amd/spec.py reads such scripts into this form):
  *   out[p] = sum_t weights[t] * in[p + (offsets[3t], offsets[3t+1], offsets[3t+2])]   (i, j, k offsets; taps added in list
- *   order).  Two shapes: any table inside the 125-point cube (every offset in [-2,2], 1 <= ntaps <= 125), or a STAR-shaped
- *   table -- every tap moves along one axis only -- with offsets up to [-4,4] (1 <= ntaps <= 64): a user-written radius-3 or
- *   radius-4 finite-difference script (the reference's generator takes any script, codegen/st/codegen/base.py:678;
- *   stencils/mpi25pt.py is radius 4).  Cube-shaped taps beyond radius 2 are refused with BRK_EINVAL.  Bricks: brick_ids_dev[0..n) when non-NULL (BRK_LIST_SKIP allowed), else
+ *   order).  Every offset in [-4,4].  Three shapes, chosen by the library: a table inside the 125-point cube (offsets in [-2,2],
+ *   ntaps <= 125: the table travels as a kernel argument); a STAR-shaped table -- every tap moves along one axis only -- up to
+ *   radius 4 with ntaps <= 64 (a user-written radius-3 or radius-4 finite-difference script; star staging); any other table of
+ *   radius 3 or 4, up to 9^3 = 729 taps (round 5: (8+2R)^3 tiles, the table kept in device memory per content -- the first call
+ *   with a new table uploads it synchronously, brk_finalize frees them).  The reference's generator takes any script
+ *   (codegen/st/codegen/base.py:678; stencils/mpi25pt.py is radius 4).  Bricks: brick_ids_dev[0..n) when non-NULL (BRK_LIST_SKIP allowed), else
  *   ids first..first+n-1.  General path: one LDS read + FMA per tap and point, not tuned like the built-in stencils. */
 int brk_stencil_apply_taps(const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
                            const uint32_t *brick_ids_dev, uint32_t first, uint32_t n, uint32_t ntaps,
@@ -172,7 +174,7 @@ int brk_stencil_apply_taps(const uint32_t *adj_dev, const double *in_dev, double
 
 /* NON-LINEAR stencils given as data (ABI 1010): the reference's generator takes any expression over grid references, constants,
  * functions and If (codegen/st/codegen/base.py:678; stencils/cond.py: max, If).  A script arrives as a register program
- * (bricklib_amd/spec.py builds it from the script; at most 120 ops, 16 registers, taps inside the 125-point cube): out[p] =
+ * (bricklib_amd/spec.py builds it from the script; at most 120 ops, 16 registers, tap offsets in [-4,4]): out[p] =
  * value of register `result_reg` after the ops have run in order for cell p.  Registers must be written before they are read.
  * The general path -- one LDS read per tap, a few instructions per op; the built-in stencils keep their tuned kernels. */
 enum { BRK_EX_TAP = 0, BRK_EX_CONST, BRK_EX_ADD, BRK_EX_SUB, BRK_EX_MUL, BRK_EX_DIV, BRK_EX_NEG, BRK_EX_MAX, BRK_EX_MIN, BRK_EX_ABS,

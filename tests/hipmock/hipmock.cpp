@@ -152,6 +152,10 @@ void run_stencil(int id, const uint32_t *adj, const double *in, double *out, siz
   orc_brick_stencil(id, adj, in, out, step, list.data(), (long)list.size(), 0, cf.c);
 }
 
+int rel_of(int R, int di, int dj, int dk) {
+  return R == 1 ? brklib::tap_rel<1>(di, dj, dk) : R == 2 ? brklib::tap_rel<2>(di, dj, dk) : R == 3 ? brklib::tap_rel<3>(di, dj, dk) : brklib::tap_rel<4>(di, dj, dk);
+}
+
 void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
   (void)block;
   if (name.find("k_link_copy") != std::string::npos) {
@@ -187,7 +191,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
       for (int dk = -R; dk <= R; ++dk)
         for (int dj = -R; dj <= R; ++dj)
           for (int di = -R; di <= R; ++di)
-            if ((R == 1 ? brklib::tap_rel<1>(di, dj, dk) : brklib::tap_rel<2>(di, dj, dk)) == pg.op[t].rel) off[0] = di, off[1] = dj, off[2] = dk;
+            if (rel_of(R, di, dj, dk) == pg.op[t].rel) off[0] = di, off[1] = dj, off[2] = dk;
       if (off[0] == 9) abort();
       std::vector<double> &g = gathered[pg.op[t].rel];
       g.assign(((size_t)top + 1) * step, 0.0);
@@ -228,6 +232,27 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
       }
     return;
   }
+  if (name.find("k_taps_far<") != std::string::npos) { // (adj, in, out, step, ids, first, n, TapsFar): table in "device" memory
+    const brklib::TapsFar t = arg<brklib::TapsFar>(args, 7);
+    const int R = (int)targs(name, "k_taps_far").at(0);
+    need("tap offsets", t.rel, (size_t)t.n * 4);
+    need("tap weights", t.w, (size_t)t.n * 8);
+    std::vector<int> off;
+    for (int q = 0; q < t.n; ++q) {
+      bool found = false;
+      for (int dk = -R; dk <= R && !found; ++dk)
+        for (int dj = -R; dj <= R && !found; ++dj)
+          for (int di = -R; di <= R && !found; ++di)
+            if (rel_of(R, di, dj, dk) == t.rel[q]) off.insert(off.end(), {di, dj, dk}), found = true;
+      if (!found) abort();
+    }
+    const std::vector<uint32_t> list = checked_list(arg<const uint32_t *>(args, 0), arg<const double *>(args, 1), arg<double *>(args, 2), arg<size_t>(args, 3),
+                                                    arg<const uint32_t *>(args, 4), arg<uint32_t>(args, 5), arg<uint32_t>(args, 6));
+    if (!list.empty())
+      orc_brick_taps(arg<const uint32_t *>(args, 0), arg<const double *>(args, 1), arg<double *>(args, 2), arg<size_t>(args, 3), list.data(), (long)list.size(), t.n,
+                     off.data(), t.w);
+    return;
+  }
   if (name.find("k_star_taps<") != std::string::npos) { // (adj, in, out, step, ids, first, n, StarTaps)
     const brklib::StarTaps t = arg<brklib::StarTaps>(args, 7);
     std::vector<int> off;
@@ -259,7 +284,7 @@ void launch(const std::string &name, dim3 grid, dim3 block, void **args) {
         for (int dk = -R; dk <= R && !found; ++dk)
           for (int dj = -R; dj <= R && !found; ++dj)
             for (int di = -R; di <= R && !found; ++di)
-              if ((R == 1 ? brklib::tap_rel<1>(di, dj, dk) : brklib::tap_rel<2>(di, dj, dk)) == t.rel[q]) off.insert(off.end(), {di, dj, dk}), found = true;
+              if (rel_of(R, di, dj, dk) == t.rel[q]) off.insert(off.end(), {di, dj, dk}), found = true;
         if (!found) abort();
       }
       const std::vector<uint32_t> list = checked_list(adj, in, out, step, ids, first, n);

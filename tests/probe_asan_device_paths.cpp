@@ -192,11 +192,18 @@ static int launches() {
     REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 3, 6, off, w, nullptr) == BRK_OK);
     const int32_t far[] = {9, 0, 0};
     REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 1, 1, 1, far, w, nullptr) != BRK_OK);
-    // star-shaped tables reach radius 4; cube-shaped ones stop at 2
+    // star-shaped and cube-shaped tables reach radius 4 (the latter with the table in device memory, kept per content)
     const int32_t star4[] = {0, 0, 0, 4, 0, 0, -3, 0, 0, 0, 4, 0, 0, -4, 0, 0, 0, 3};
     REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 3, 6, star4, w, nullptr) == BRK_OK);
-    const int32_t cube3[] = {3, 1, 0};
-    REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 1, 1, cube3, w, nullptr) != BRK_OK);
+    const int32_t cube3[] = {3, 1, 0, -2, 3, -3};
+    REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 1, 2, cube3, w, nullptr) == BRK_OK);
+    REQ(std::string(brk_last_kernel()) == "k_taps_far<3,2>");
+    REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 2, 2, cube3, w, nullptr) == BRK_OK); // the cached table
+    const int32_t cube4[] = {4, -4, 1};
+    REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 1, 1, cube4, w, nullptr) == BRK_OK);
+    REQ(std::string(brk_last_kernel()) == "k_taps_far<4,1>");
+    const int32_t cube5[] = {5, 1, 0};
+    REQ(brk_stencil_apply_taps(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 1, 1, cube5, w, nullptr) != BRK_OK);
   }
   // stencil given as a register program: |max(in, 0) * in(i+2, j-1, k+1) - 0.5|, then the argument checks
   {
@@ -222,7 +229,11 @@ static int launches() {
     ops[4].b = 9;
     REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 0, 3, ops, 7, 2, nullptr) != BRK_OK); // read before written
     ops[4].b = 1, ops[3].offset[2] = 3;
-    REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 0, 3, ops, 7, 2, nullptr) != BRK_OK); // outside the 125-point cube
+    REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 2, ops, 7, 2, nullptr) == BRK_OK && std::string(brk_last_kernel()) == "k_expr<3,2>");
+    ops[3].offset[0] = -4;
+    REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 7 * 6 * 2 + 7 * 2 + 2, 2, ops, 7, 2, nullptr) == BRK_OK && std::string(brk_last_kernel()) == "k_expr<4,1>");
+    ops[3].offset[1] = 5;
+    REQ(brk_stencil_apply_expr(adj_dev, in, out, 512, nullptr, 0, 3, ops, 7, 2, nullptr) != BRK_OK); // beyond radius 4
   }
   // array <-> brick, compare
   {

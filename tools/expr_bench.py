@@ -81,6 +81,25 @@ def main():
     timed("radius-2 limiter, interpreted", lambda: bl.apply_expr(lim, A, B, ids=ids))
     c2 = bl.CompiledExpr(lim)
     timed("radius-2 limiter, compiled", lambda: c2.apply(A, B, ids=ids))
+    # beyond the 125-point cube: (8 + 2R)^3 tiles, 2 / 1 waves per workgroup
+    import itertools
+    for r in (2, 3, 4):
+        cube = [((di, dj, dk), 1.0 / (1 + abs(di) + abs(dj) + abs(dk))) for dk, dj, di in itertools.product(range(-r, r + 1), repeat=3)]
+        timed(f"all {len(cube)} taps of the radius-{r} cube (tap path)", lambda: bl.apply_taps(cube, A, B, ids=ids))
+    far = load_spec(HEAD + """
+hi = Func("max", 2)
+v(i, j, k).assign(hi(u(i + 3, j - 3, k + 1), u(i - 2, j + 3, k - 3)) * u(i, j, k) - u(i - 3, j, k))
+STENCIL = [v]
+""")
+    timed("radius-3 off-axis max/product, interpreted", lambda: bl.apply_expr(far, A, B, ids=ids))
+    c3 = bl.CompiledExpr(far)
+    timed("radius-3 off-axis max/product, compiled", lambda: c3.apply(A, B, ids=ids))
+    far4 = load_spec(HEAD + """
+v(i, j, k).assign(If(u(i + 4, j - 4, k + 4) > u(i - 4, j + 1, k - 2), u(i, j + 4, k), u(i - 1, j, k) * u(i, j, k)))
+STENCIL = [v]
+""")
+    c4 = bl.CompiledExpr(far4)
+    timed("radius-4 off-axis If, compiled", lambda: c4.apply(A, B, ids=ids))
 
 
 if __name__ == "__main__":

@@ -263,7 +263,7 @@ ichunk)  # round 5: rows of a block cut along i into chunks (kbench -C): the k-r
   for sid in 4 3; do for c in 0 32 16; do run -n 512 -s $sid -S -Q -o 8 -C $c -PP -v 100 -i 60 -r2 2; done; done
   for sid in 1 5 7 0; do for c in 0 32; do run -n 512 -s $sid -S -Q -o 8 -C $c -v 100 -i 40 -r2 2; done; done ;;
 expr)    # round 5: the expression path (non-linear scripts): new GPU tests, then ms per 512^3 sweep beside the tuned cond kernel and the tap path
-  timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_cpp_headers.py -m gpu -q -x --timeout=300 -k "expression or single_hip or compiled" > gpurun_out/pytest_expr.log 2>&1; rc=$?
+  timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_cpp_headers.py -m gpu -q -x --timeout=300 -k "expression or single_hip or compiled or taps" > gpurun_out/pytest_expr.log 2>&1; rc=$?
   tail -5 gpurun_out/pytest_expr.log
   if [ $rc -ne 0 ]; then exit 1; fi
   timeout -k 10 300 python tools/expr_bench.py ;;
