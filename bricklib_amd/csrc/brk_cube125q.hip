@@ -288,7 +288,7 @@ int all_regular(const uint32_t *ids, uint32_t n, const uint32_t *mask, hipStream
 int launch_cube125_q(const uint32_t *adj, const double *in, double *out, size_t step, const uint32_t *ids, uint32_t n, const Coeffs &cf, hipStream_t st,
                      uint32_t s1, uint32_t s2, bool predicted) {
   const uint32_t wgs4 = (((n + 3) / 4 + 7) / 8) * 8;
-  brk_note_kernel(predicted ? "k_cube125_q<1>" : "k_cube125_q<0>");
+  brki_note_kernel(predicted ? "k_cube125_q<1>" : "k_cube125_q<0>");
   if (predicted) hipLaunchKernelGGL((k_cube125_q<1>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, n, cf, s1, s2);
   else hipLaunchKernelGGL((k_cube125_q<0>), dim3(wgs4), dim3(256), 0, st, adj, in, out, step, ids, n, cf, s1, s2);
   HIP_TRY(hipGetLastError());

@@ -545,7 +545,7 @@ int launch_cube_dense(int stencil_id, int variant, const uint32_t *adj, const do
   const bool x2 = stencil_id == BRK_MPI7_X2 || stencil_id == BRK_7PT_X2;
 #define BRK_CD(KIND, NW, OCC, PIPE, WGS, LDS)                                                                                          \
   do {                                                                                                                                 \
-    brk_note_kernel("k_cube_dense<" #KIND "," #NW "," #OCC "," #PIPE ">");                                                             \
+    brki_note_kernel("k_cube_dense<" #KIND "," #NW "," #OCC "," #PIPE ">");                                                             \
     hipLaunchKernelGGL((k_cube_dense<KIND, NW, OCC, PIPE>), dim3(WGS), dim3(64 * NW), LDS, st, adj, in, out, step, ids, first, n, cf, \
                        g_diag, linkmask, cubereg.mask, cubereg.s1, cubereg.s2);                                                        \
   } while (0)

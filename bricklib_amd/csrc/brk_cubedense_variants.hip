@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube125_q(const uint32_t *__re
   if (variant == 15 && linkmask && cubereg.faces) { // registered tables: the LDS-DMA staged kernels (slower; see k_cube_dma)
 #define BRK_CDMA(KIND, NW, OCC, PIPE)                                                                                                                    \
   do {                                                                                                                                                  \
-    brk_note_kernel("k_cube_dma<" #KIND "," #NW "," #OCC "," #PIPE ">");                                                                                \
+    brki_note_kernel("k_cube_dma<" #KIND "," #NW "," #OCC "," #PIPE ">");                                                                                \
     hipLaunchKernelGGL((k_cube_dma<KIND, NW, OCC, PIPE>), dim3(wgs4), dim3(64 * NW), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, linkmask, \
                        cubereg.faces, cubereg.mask, cubereg.s1, cubereg.s2);                                                                            \
   } while (0)
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube125_q(const uint32_t *__re
     return BRK_OK;
   }
   if (stencil_id == BRK_MPI125 && (variant == 16 || variant == 17)) { // round-5 experiment: the lean 125-point kernel at 4 waves per SIMD in groups of 4 (16) / 8 (17) waves (timing diagnostic, wrong i-ends)
-    brk_note_kernel(variant == 16 ? "k_cube125_q<4,4,0>" : "k_cube125_q<8,4,0>");
+    brki_note_kernel(variant == 16 ? "k_cube125_q<4,4,0>" : "k_cube125_q<8,4,0>");
     if (variant == 16) hipLaunchKernelGGL((k_cube125_q<4, 4, 0>), dim3(wgs4), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf);
     else hipLaunchKernelGGL((k_cube125_q<8, 4, 0>), dim3((((n + 7) / 8 + 7) / 8) * 8), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, cf); // 17: 8-wave groups, 2 per CU
     HIP_TRY(hipGetLastError());

@@ -9,18 +9,18 @@ int brk_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)
 #ifdef __cplusplus
 extern "C"
 #endif
-void brk_note_kernel(const char *name);
+void brki_note_kernel(const char *name);
 
 // brk_stencil_apply_expr / brk_expr_compile: known codes, registers in range and written before they are read, taps inside the 125-point
 // cube; *radius = 1 or 2.  BRK_OK or a recorded failure.
 #ifdef __cplusplus
 extern "C"
 #endif
-int brk_expr_check(const brk_expr_op *ops, uint32_t nops, uint32_t result_reg, int *radius);
+int brki_expr_check(const brk_expr_op *ops, uint32_t nops, uint32_t result_reg, int *radius);
 #ifdef __cplusplus
 extern "C"
 #endif
-void brk_jit_finalize(void); // brk_finalize: unload the modules of brk_expr_compile
+void brki_jit_finalize(void); // brk_finalize: unload the modules of brk_expr_compile
 enum { BRK_EXPR_MAX_OPS = 120, BRK_EXPR_MAX_REGS = 16 }; // = kMaxExprOps, kMaxExprRegs of brick-device.h (static_assert in brk_kernels.hip)
 
 #ifdef __cplusplus

@@ -776,7 +776,7 @@ static int far_table_locked(int radius, uint32_t ntaps, const int32_t *offsets, 
 
 extern "C" int brk_finalize(void) {
   HIP_TRY(hipDeviceSynchronize());
-  brk_jit_finalize();
+  brki_jit_finalize();
   int device = 0;
   HIP_TRY(hipGetDevice(&device));
   {
@@ -877,10 +877,10 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
       if (int rc = far_table_locked(maxabs, ntaps, offsets_host, weights_host, &tf)) return rc;
     }
     if (maxabs == 3) {
-      brk_note_kernel("k_taps_far<3,2>");
+      brki_note_kernel("k_taps_far<3,2>");
       hipLaunchKernelGGL((k_taps_far<3, 2>), dim3((((n + 1) / 2 + 7) / 8) * 8), dim3(128), 0, st, adj, in, out, step, ids, first, n, tf);
     } else {
-      brk_note_kernel("k_taps_far<4,1>");
+      brki_note_kernel("k_taps_far<4,1>");
       hipLaunchKernelGGL((k_taps_far<4, 1>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, tf);
     }
     HIP_TRY(hipGetLastError());
@@ -896,7 +896,7 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
       sp.off[t] = dk ? dk : (dj ? dj : di);
       sp.w[t] = weights_host[t];
     }
-    brk_note_kernel("k_star_taps<4>");
+    brki_note_kernel("k_star_taps<4>");
     hipLaunchKernelGGL((k_star_taps<4>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, sp);
     HIP_TRY(hipGetLastError());
     return BRK_OK;
@@ -911,7 +911,7 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
     tp.w[t] = weights_host[t];
   }
   const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
-  brk_note_kernel(tp.radius == 1 ? "k_taps<1,4>" : "k_taps<2,4>");
+  brki_note_kernel(tp.radius == 1 ? "k_taps<1,4>" : "k_taps<2,4>");
   if (tp.radius == 1) hipLaunchKernelGGL((k_taps<1, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);
   else hipLaunchKernelGGL((k_taps<2, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, tp);
   HIP_TRY(hipGetLastError());
@@ -925,7 +925,7 @@ extern "C" int brk_stencil_apply_expr(const uint32_t *adj, const double *in, dou
   if (n == 0) return ops_host && nops ? BRK_OK : brk_fail(BRK_EINVAL, "1..%d ops expected (got %u)", kMaxExprOps, nops);
   static_assert(kMaxExprOps == BRK_EXPR_MAX_OPS && kMaxExprRegs == BRK_EXPR_MAX_REGS && (int)EX_SEL == (int)BRK_EX_SEL, "brk_internal.h / brk.h disagree with brick-device.h");
   int radius = 1;
-  if (int rc = brk_expr_check(ops_host, nops, result_reg, &radius)) return rc;
+  if (int rc = brki_expr_check(ops_host, nops, result_reg, &radius)) return rc;
   ExprProg pg;
   std::memset(&pg, 0, sizeof pg);
   pg.n = (int)nops, pg.radius = radius, pg.result = (int)result_reg;
@@ -940,7 +940,7 @@ extern "C" int brk_stencil_apply_expr(const uint32_t *adj, const double *in, dou
   hipStream_t st = static_cast<hipStream_t>(s);
   const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
   static const char *const names[] = {"k_expr<1,4>", "k_expr<2,4>", "k_expr<3,2>", "k_expr<4,1>"};
-  brk_note_kernel(names[pg.radius - 1]);
+  brki_note_kernel(names[pg.radius - 1]);
   if (pg.radius == 1) hipLaunchKernelGGL((k_expr<1, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, pg);
   else if (pg.radius == 2) hipLaunchKernelGGL((k_expr<2, 4>), dim3(wgs), dim3(256), 0, st, adj, in, out, step, ids, first, n, pg);
   else if (pg.radius == 3) hipLaunchKernelGGL((k_expr<3, 2>), dim3((((n + 1) / 2 + 7) / 8) * 8), dim3(128), 0, st, adj, in, out, step, ids, first, n, pg);

@@ -334,7 +334,7 @@ int launch_star7(int stencil_id, int variant, const uint32_t *adj, const double 
   // wave with every face gathered
 #define BRK_LAUNCH_WG(M, W, I)                                                                                                                      \
   do {                                                                                                                                             \
-    brk_note_kernel("k_s7_wg<" #M "," #W "," #I ">");                                                                                              \
+    brki_note_kernel("k_s7_wg<" #M "," #W "," #I ">");                                                                                              \
     hipLaunchKernelGGL((k_s7_wg<M, W, I>), dim3(wgs), dim3(64 * W), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf, nullptr, faces); \
   } while (0)
 #define BRK_LAUNCH_WG_K(K, W)                      \
@@ -390,7 +390,7 @@ int launch_star7_box(int stencil_id, const uint32_t *adj, const double *in, doub
     return BRK_OK;
   }
 #endif
-  brk_note_kernel(stencil_id == BRK_MPI7 ? "k_s7_wg<kMpi,8,kModeBox>" : (stencil_id == BRK_COND7 ? "k_s7_wg<kCond,8,kModeBox>" : "k_s7_wg<kCoeff,8,kModeBox>"));
+  brki_note_kernel(stencil_id == BRK_MPI7 ? "k_s7_wg<kMpi,8,kModeBox>" : (stencil_id == BRK_COND7 ? "k_s7_wg<kCond,8,kModeBox>" : "k_s7_wg<kCoeff,8,kModeBox>"));
   if (stencil_id == BRK_MPI7)
     hipLaunchKernelGGL((k_s7_wg<kMpi, 8, kModeBox>), dim3(8 * per_xcd), dim3(512), g_pad_lds, st, adj, in, out, step, nullptr, 0u, n, bx, cf, regmask, faces);
   else if (stencil_id == BRK_COND7)

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_s7_km(const uint32_t *__restri
     if (ids) hipLaunchKernelGGL((k_s7_wg<K, 8, kModeList, 0, 1>), dim3(wgs), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf, nullptr, faces); \
     else hipLaunchKernelGGL((k_s7_wg<K, 8, kModeRange, 0, 1>), dim3(wgs), dim3(512), g_pad_lds, st, adj, in, out, step, ids, first, n, Box{}, cf, nullptr, faces);   \
   } while (0)
-    brk_note_kernel("k_s7_wg<.,8,.,0,IDPP=1>");
+    brki_note_kernel("k_s7_wg<.,8,.,0,IDPP=1>");
     if (kind == kMpi) BRK_LAUNCH_DPP(kMpi);
     else if (kind == kCond) BRK_LAUNCH_DPP(kCond);
     else BRK_LAUNCH_DPP(kCoeff);

@@ -477,14 +477,14 @@ int launch_star_wg(int stencil_id, int variant, const uint32_t *adj, const doubl
   // brick at a time: 0.565 / 0.445 ms) -- declare only what is true.  -DBRK_VARIANTS builds: variant 3 = k_star_kp.
   if (kpaired) {
     const uint32_t wgs8 = (((n + 7) / 8 + 7) / 8) * 8;
-    brk_note_kernel(stencil_id == BRK_MPI13 ? "k_star_km<kStarMpi13,2,4>" : "k_star_km<kStarMpi25,2,3>");
+    brki_note_kernel(stencil_id == BRK_MPI13 ? "k_star_km<kStarMpi13,2,4>" : "k_star_km<kStarMpi25,2,3>");
     if (stencil_id == BRK_MPI13) hipLaunchKernelGGL((k_star_km<kStarMpi13, 2, 4>), dim3(wgs8), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
     else hipLaunchKernelGGL((k_star_km<kStarMpi25, 2, 3>), dim3(wgs8), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
     HIP_TRY(hipGetLastError());
     return BRK_OK;
   }
   const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
-  brk_note_kernel(stencil_id == BRK_MPI13 ? "k_star_wg<kStarMpi13,4,5>" : "k_star_wg<kStarMpi25,4,3>");
+  brki_note_kernel(stencil_id == BRK_MPI13 ? "k_star_wg<kStarMpi13,4,5>" : "k_star_wg<kStarMpi25,4,3>");
   if (stencil_id == BRK_MPI13)
     hipLaunchKernelGGL((k_star_wg<kStarMpi13, 4, 5>), dim3(wgs), dim3(256), g_pad_lds, st, adj, in, out, step, ids, first, n, cf, faces);
   else

@@ -169,12 +169,12 @@ class Oracle:
         The checker of brk_stencil_apply_expr."""
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         cache = {}
+        tmp = np.zeros_like(bin_)       # one scratch field: orc_brick_taps writes the listed bricks only
 
         def tap(off):
             if off not in cache:
-                tmp = np.zeros_like(bin_)
                 self.brick_taps(adj, bin_, tmp, step, ids, [(off, 1.0)])
-                cache[off] = tmp.reshape(-1, step)[ids][:, :512]
+                cache[off] = tmp.reshape(-1, step)[ids][:, :512].copy()
             return cache[off]
         val = np.broadcast_to(np.asarray(spec.evaluate(tap, constants), dtype=np.float64), (ids.size, 512))
         bout.reshape(-1, step)[ids, :512] = val

@@ -1074,6 +1074,46 @@ def test_compiled_expression_lifecycle(dev):
     assert lib.brk_expr_release(C.c_void_p(handle)) != 0               # gone already
 
 
+def test_scripts_at_baseline_size_512(oracle, dev):
+    """BASELINE size (512^3, 262144 bricks) for stencils given as data: the cond-shaped script compiled at run time against the tuned
+    d3cond kernel over the whole field; a homogeneous script (degree 1: |sum c max(u, 0)|) scales with positive factors; the compiled
+    and the interpreted form agree bit for bit on every brick; 512 random bricks against the oracle's evaluation of the tree; bricks
+    outside the list are untouched."""
+    from bricklib_amd.order import tiled
+    from bricklib_amd.spec import load_spec
+    SB = 66
+    grid, info = bl.init_grid((SB, SB, SB), dev)
+    g3 = grid.reshape(SB, SB, SB)
+    ids = tiled(g3[1:-1, 1:-1, 1:-1])
+    ids_dev = grid_to_device(ids, dev)
+    coeff = oracle.coeffs(129, 1) - 0.45
+    spec = load_spec(EXPR_SCRIPTS["cond"])
+    x, a, b, c = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(4))
+    x.dat.uniform_(-0.5, 0.5)
+    B = lambda s: bl.Brick(info, s, 0)
+    ck = bl.CompiledExpr(spec, {"coeff": coeff})
+    ck.apply(B(x), B(a), ids=ids_dev)
+    bl.apply_stencil("cond", B(x), B(b), ids=ids_dev, coeff=coeff)
+    assert (a.dat - b.dat).abs().max().item() <= TOL and a.dat.abs().max().item() > 0.1
+    bl.apply_expr(spec, B(x), B(c), ids=ids_dev, constants={"coeff": coeff})
+    assert torch.equal(a.dat, c.dat)
+    real = ids[ids != 0xFFFFFFFF]
+    mask = torch.ones(info.nbricks, dtype=torch.bool, device=dev)
+    mask[torch.from_numpy(real.astype(np.int64)).to(dev)] = False
+    assert (a.dat.view(-1, 512)[mask] == 0).all()
+    z = bl.BrickStorage(3.0 * x.dat, info.nbricks, 512)
+    ck.apply(B(z), B(c), ids=ids_dev)
+    assert (c.dat - 3.0 * a.dat).abs().max().item() <= 1e-13
+    rng = np.random.default_rng(5)
+    sub = np.sort(rng.choice(real, 512, replace=False)).astype(np.uint32)
+    hin = x.dat.cpu().numpy()
+    want = np.zeros_like(hin)
+    oracle.brick_expr(spec, info.adj_host, hin, want, 512, sub, {"coeff": coeff})
+    got = a.dat.view(-1, 512)[torch.from_numpy(sub.astype(np.int64)).to(dev)].cpu().numpy()
+    assert np.array_equal(got, want.reshape(-1, 512)[sub])
+    ck.release()
+
+
 def test_expression_argument_checks(dev):
     """a program is checked before anything is launched: unknown codes, registers out of range or read before written, taps
     outside the 125-point cube, too many operations"""
