@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0
 BYTES_PER_UPDATE = 16.0        # one fp64 read + one fp64 write per lattice update
+FP64_VECTOR_TFLOPS = 78.65     # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector 157.3 TFLOP/s; fp64 FMA issues at half that rate
 
 
 def parse():
@@ -238,6 +239,14 @@ def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, 
          "sweep_direction": "alternating" if zigzag else "one way", "GStencil/s": cells / (ms * 1e-3) / 1e9, "launches": launches,
          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                       "frac_of_measured_copy": ach / HBM_COPY_GBS, "kernel": bl.last_kernel()}}
+    # every stencil here is HBM-bound by arithmetic intensity; the 125-point one only with coefficient grouping (134 flop
+    # per point, the reference's ST_CPU form) -- "report both rooflines for it".  Algorithmic flop per point, not instructions executed
+    # (the kernels fold symmetric taps before multiplying); peak = the fp64 vector rate, half of the guide's 157.3 TFLOP/s fp32 vector.
+    flop = {"7pt": 13, "mpi7pt": 13, "mpi13pt": 25, "mpi25pt": 49, "27pt": 53, "mpi125pt": 134}.get(name)
+    if flop:
+        tf = flop * cells / (ms * 1e-3) / 1e12
+        r["roofline_fp64_vector"] = {"bound": "valu", "flop_per_point": flop, "achieved": tf, "peak": FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": tf / FP64_VECTOR_TFLOPS}
     if O is not None:
         r["max_abs_err_vs_oracle"] = verify_sample(bl, O, sid, info, st, sto, step_e, off_out, ids, coeff, nsample=nsample)
     return r
