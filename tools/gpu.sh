@@ -267,6 +267,9 @@ expr)    # round 5: the expression path (non-linear scripts): new GPU tests, the
   tail -5 gpurun_out/pytest_expr.log
   if [ $rc -ne 0 ]; then exit 1; fi
   timeout -k 10 300 python tools/expr_bench.py ;;
+big13)   # round 5: the 13-point star on ONE 1024^3 grid (rows of 128 bricks: a block of 8 rows is 4 MiB = the L2 of an XCD): i-chunks of 64 / 32 bricks vs none; 512^3 beside it
+  for c in 0 64 32; do run -n 1024 -s 3 -S -o 8 -C $c -PP -v 100 -i 20 -r2 2; done
+  for c in 0 32; do run -n 512 -s 3 -S -o 8 -C $c -PP -v 100 -i 60 -r2 2; done ;;
 reg7)    # 7-point box kernel with / without brk_adjacency_register
   for r in 1 2 3; do run -n 512 -s 0 -S -b -v 0 -i 60; run -n 512 -s 0 -S -b -v 0 -i 60 -R; done ;;
 order7)  # 7-point list form: rows per block of the XCD slab order
