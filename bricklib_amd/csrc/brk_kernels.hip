@@ -872,10 +872,8 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
   if (maxabs > 4) return brk_fail(BRK_EINVAL, "taps reach offset %d: tables are limited to [-4,4] per axis", maxabs);
   if (maxabs > 2 && (!star || ntaps > (uint32_t)kMaxStarTaps)) {
     TapsFar tf;
-    {
-      std::lock_guard<std::mutex> lock(g_far_mutex);
-      if (int rc = far_table_locked(maxabs, ntaps, offsets_host, weights_host, &tf)) return rc;
-    }
+    std::lock_guard<std::mutex> lock(g_far_mutex); // until the launch is enqueued: an eviction by another thread drains the device first, then frees
+    if (int rc = far_table_locked(maxabs, ntaps, offsets_host, weights_host, &tf)) return rc;
     if (maxabs == 3) {
       brki_note_kernel("k_taps_far<3,2>");
       hipLaunchKernelGGL((k_taps_far<3, 2>), dim3((((n + 1) / 2 + 7) / 8) * 8), dim3(128), 0, st, adj, in, out, step, ids, first, n, tf);
