@@ -32,7 +32,7 @@ namespace brklib {
 namespace {
 
 struct QL { // one 4-wave group in LDS, offsets in doubles
-  static constexpr int NW = 4, T = 12;
+  static constexpr int NW = 4;
   __host__ __device__ static constexpr bool khalo(int p) { return p < 2 || p >= 10; }
   __host__ __device__ static constexpr int psize(int p) { return NW * 96 + (khalo(p) ? 32 : 48); }
   __host__ __device__ static constexpr int off(int p) {

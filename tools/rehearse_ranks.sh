@@ -23,6 +23,22 @@ assert c["conservation_rel_drift"] < 1e-12
 assert len(c["ranks_seen"]) == d["n_gpus"] and "scaling_base" in d
 PY
 done
+# the star stencils of the weak workload: k-paired lists (13- and 25-point), i-chunked blocks (25-point)
+for st in mpi13pt mpi25pt; do
+  port=$((port + 1))
+  out=gpurun_out/rehearse/n2_auto_$st
+  timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $port \
+    bench.py --gpus 2 --backend gloo --cells 256 --steps 3 --warmup 1 --no-cpu-baseline --stencil $st > $out.out 2> $out.err
+  rc=$?
+  if [ $rc -ne 0 ]; then echo "N=2 $st FAILED rc=$rc"; tail -15 $out.err; exit 1; fi
+  python3 - $out.out "2 auto $st" <<'PY'
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+c = d["config"]
+print(sys.argv[2], "schedule", c["schedule"], "conservation drift", c["conservation_rel_drift"], "kernel", d["roofline"].get("kernel", "")[:60])
+assert c["conservation_rel_drift"] < 1e-12
+PY
+done
 # strong workload: global 256^3 in 64^3 subdomains over 2 and 3 ranks
 for np_ in 2 3; do
   port=$((port + 1))
