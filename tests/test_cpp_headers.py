@@ -144,6 +144,53 @@ __global__ void kern(B bIn, B bOut, const double *coeff, unsigned b) { brick("mi
     assert "::brklib::brick_apply_fn<1>(" in text and "(coeff[0])" in text and 'brick("minmod.py"' not in text
 
 
+def test_radius3_cube_script_goes_to_the_table_form(tmp_path):
+    """tools/brkscatter on examples/blur343.py (343 taps, radius 3): the brick(...) line becomes brick_apply_taps_table<3, 343> (tap
+    table in LDS, rolled tap loop), the tile(...) line plain loops whose host build agrees with numpy over a 14^3 window."""
+    import ctypes as C
+    import shutil
+    from bricklib_amd.spec import load_spec
+    shutil.copy(os.path.join(ROOT, "examples", "blur343.py"), tmp_path / "blur343.py")
+    src = tmp_path / "t.cpp"
+    src.write_text("""#include "vecscatter.h"
+#define bIn(a, b, c) in[c][b][a]
+#define bOut(a, b, c) out[c][b][a]
+#ifndef BRK_SCATTER_PASS
+static const long hipThreadIdx_x = 0, hipBlockDim_x = 1;
+#endif
+extern "C" void run(const double (*in)[14][14], double (*out)[14][14], const double *coeff) {
+  long i = 3, j = 3, k = 3;
+  tile("blur343.py", "HIP", (8, 8, 8), ("k", "j", "i"));
+}
+#ifdef WITH_BRICK
+struct B { struct { unsigned (*adj)[27]; } *bInfo; double *dat; unsigned long step; };
+__global__ void kern(B bIn, B bOut, const double *coeff, unsigned b) { brick("blur343.py", "HIP", (8, 8, 8), (8, 8), b); }
+#endif
+""")
+    out = tmp_path / "t-out.cpp"
+    tool = os.path.join(ROOT, "tools", "brkscatter")
+    r = subprocess.run([sys.executable, tool, str(src), str(out), "--", "-I" + os.path.join(ROOT, "include")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0 and b"0 brick(...) and 1 tile(...)" in r.stdout, r.stdout.decode()
+    so = tmp_path / "t.so"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "include"), str(out), "-o", str(so)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    rng = np.random.default_rng(6)
+    a = rng.random((14, 14, 14)) - 0.5
+    got = np.zeros_like(a)
+    coeff = rng.random(10)
+    C.CDLL(str(so)).run(a.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), coeff.ctypes.data_as(C.c_void_p))
+    spec = load_spec(str(tmp_path / "blur343.py"))
+    assert spec.linear and spec.radius == 3 and len(spec.offsets) == 343
+    want = sum(w * a[3 + o[2]:11 + o[2], 3 + o[1]:11 + o[1], 3 + o[0]:11 + o[0]] for o, w in spec.taps({"coeff": coeff}))
+    assert np.abs(got[3:11, 3:11, 3:11] - want).max() <= 1e-13 and not got[:3].any()
+    r = subprocess.run([sys.executable, tool, str(src), str(out), "--", "-DWITH_BRICK", "-I" + os.path.join(ROOT, "include")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    assert r.returncode == 0 and b"1 brick(...) and 1 tile(...)" in r.stdout, r.stdout.decode()
+    text = out.read_text()
+    assert "::brklib::brick_apply_taps_table<3, 343>(" in text and "::brklib::tap_rel<3>(-3, -3, -3)" in text
+
+
 REF = "/root/reference"
 REF_EXE = os.path.join(ROOT, "examples", "_ref", "single_hip_ref")
 
