@@ -1114,6 +1114,33 @@ def test_scripts_at_baseline_size_512(oracle, dev):
     ck.release()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 5, 8, 13, 21, 34])
+def test_random_scripts_interpreted_compiled_and_oracle_agree(oracle, dev, seed):
+    """seeded random expression DAGs (tests/random_scripts.py; radius 1..4, shared sub-expressions, If / comparisons / max / min /
+    abs): brk_stencil_apply_expr, the run-time compiled kernel and the oracle's evaluation of the tree agree BIT FOR BIT on a BrickDecomp
+    numbering incl. the ghost ring (neighbours that are the dummy brick 0)"""
+    from random_scripts import random_script
+    from bricklib_amd.spec import load_spec
+    spec = load_spec(random_script(seed, radius=1 + seed % 4, steps=30))
+    consts = {"cA": 0.3}
+    d = bl.BrickDecomp((24, 16, 32))
+    dinfo = d.getBrickInfo(dev)
+    A, B, C = (dinfo.allocate(512, dev) for _ in range(3))
+    A.dat.uniform_(-0.5, 0.5)
+    A.dat[:512] = 0
+    rng = (1, d.sep_pos[2])
+    bl.apply_expr(spec, bl.Brick(dinfo, A, 0), bl.Brick(dinfo, B, 0), brick_range=rng, constants=consts)
+    ck = bl.CompiledExpr(spec, consts)
+    ck.apply(bl.Brick(dinfo, A, 0), bl.Brick(dinfo, C, 0), brick_range=rng)
+    ck.release()
+    assert torch.equal(B.dat, C.dat)
+    hin = A.dat.cpu().numpy()
+    want = np.zeros_like(hin)
+    oracle.brick_expr(spec, d.adj, hin, want, 512, np.arange(rng[0], rng[1], dtype=np.uint32), consts)
+    got = B.dat.cpu().numpy()
+    assert np.array_equal(got, want) and np.unique(want).size > 1000
+
+
 def test_expression_argument_checks(dev):
     """a program is checked before anything is launched: unknown codes, registers out of range or read before written, taps
     outside the 125-point cube, too many operations"""

@@ -219,3 +219,34 @@ def test_expression_source_generation_and_compilation_without_a_device():
         return
     with pytest.raises(BrkError, match="compiled for gfx950 .* no device|libhiprtc"):
         CompiledExpr(s, {"lim": 0.75})
+
+
+@pytest.mark.parametrize("steps", [14, 45])
+def test_random_scripts_compile_to_equivalent_programs(steps):
+    """seeded random expression DAGs (tests/random_scripts.py: shared sub-expressions, If, comparisons, max / min / abs, radius 1..4):
+    the register program interpreted on the host equals the tree's evaluation bit for bit; the few that need more than 16 live values
+    or 120 operations say so"""
+    import numpy as np
+    from random_scripts import random_script
+    from bricklib_amd.spec import MAX_OPS, MAX_REGS
+    from bricklib_amd.stencils import expr_source
+    compiled = refused = 0
+    for seed in range(40):
+        s = load_spec(random_script(seed, radius=1 + seed % 4, steps=steps))
+        try:
+            ops, result = s.program({"cA": 0.3})
+        except ValueError as e:
+            assert "values at once" in str(e) or "operations" in str(e)
+            refused += 1
+            continue
+        assert len(ops) <= MAX_OPS and all(o[q] < MAX_REGS for o in ops for q in ("dst", "a", "b", "c"))
+        rng = np.random.default_rng(seed)
+        vals = {}
+
+        def tap(off):
+            return vals.setdefault(tuple(off), rng.random(1500) - 0.5)
+        assert np.array_equal(run_program(ops, result, tap), s.evaluate(tap, {"cA": 0.3})), seed
+        if seed % 8 == 0:
+            assert f"return r{result};" in expr_source(s, {"cA": 0.3})
+        compiled += 1
+    assert compiled >= 30, (compiled, refused)
