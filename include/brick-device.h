@@ -1062,6 +1062,32 @@ __device__ __forceinline__ void brick_apply_star_taps_static(const uint32_t *adj
   }
 }
 
+// waves of one workgroup that fit the 64 KiB of static LDS with a StarTile<R> each
+template <int R>
+struct StarWaves {
+  static constexpr int WAVES = R <= 2 ? 4 : 2;
+};
+
+// A STAR-shaped expression known at compile time (every grid reference moves along one axis: finite-difference scripts with limiters,
+// the shape of stencils/cond.py): the star staging -- own brick and its six faces, no edge or corner gathers -- and f(ti, tj, ck) per
+// cell, where in[p + (d, 0, 0)] is ti[d], in[p + (0, d, 0)] is tj[8 * d] and in[p + (0, 0, d)] is ck[d] (the lane's k-column, in registers).
+// What brk_expr_compile and tools/brkscatter emit for such scripts instead of brick_apply_fn.
+template <int R, int MAXW = StarWaves<R>::WAVES, class F>
+__device__ __forceinline__ void brick_apply_star_fn(const uint32_t *adj, const double *in, double *out, size_t step, uint32_t b, F f) {
+  using TL = StarTile<R>;
+  static_assert(MAXW * TL::ELEMS * 8 <= 65536, "tiles exceed the static LDS of a workgroup");
+  __shared__ double lds[MAXW * TL::ELEMS];
+  const int lane = threadIdx.x & 63, hi = lane >> 3, lo = lane & 7;
+  double *tile = lds + (threadIdx.x >> 6) * TL::ELEMS;
+  b = __builtin_amdgcn_readfirstlane(b);
+  double col[8 + 2 * R];
+  star_stage<R>(tile, adj, in, step, b, lane, col);
+  wave_lds_sync();
+  double *dst = out + (size_t)b * step;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], f(tile + TL::ti(k, hi, lo + R), tile + TL::tj(k, hi + R, lo), &col[R + k]));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Entry points for user kernels (one wave per brick, any number of waves per block up to MAXW).
 // in/out: field base pointers (Brick::dat), step: Brick::step, adj: BrickInfo::adj as uint32_t[nbricks][27],

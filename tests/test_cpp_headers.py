@@ -141,7 +141,7 @@ __global__ void kern(B bIn, B bOut, const double *coeff, unsigned b) { brick("mi
                        stderr=subprocess.STDOUT)
     assert r.returncode == 0 and b"1 brick(...) and 1 tile(...)" in r.stdout, r.stdout.decode()
     text = out.read_text()
-    assert "::brklib::brick_apply_fn<1>(" in text and "(coeff[0])" in text and 'brick("minmod.py"' not in text
+    assert "::brklib::brick_apply_star_fn<1>(" in text and "(coeff[0])" in text and 'brick("minmod.py"' not in text     # star-shaped: star staging
 
 
 def test_radius3_cube_script_goes_to_the_table_form(tmp_path):

@@ -1015,8 +1015,9 @@ def test_stencil_given_as_expression(oracle, dev, case):
     ck = bl.CompiledExpr(spec, consts)
     sc = bl.BrickStorage.allocate(info.nbricks, 512, dev)
     ck.apply(bl.Brick(info, st, 0), bl.Brick(info, sc, 0), ids=grid_to_device(lst, dev))
-    assert bl.last_kernel() == "k_expr_jit<%d>" % spec.radius
-    assert torch.equal(sc.dat, so.dat) and "brick_apply_fn" in ck.source
+    star = all(sum(1 for x in o["offset"] if x) <= 1 for o in spec.program(consts)[0])       # every tap on one axis: star staging
+    assert bl.last_kernel() == "k_expr_jit<%d%s>" % (spec.radius, ",star" if star else "") and star == (case in ("cond", "norm"))
+    assert torch.equal(sc.dat, so.dat) and ("brick_apply_star_fn" if star else "brick_apply_fn<") in ck.source
     if case == "cond":
         sb = bl.BrickStorage.allocate(info.nbricks, 512, dev)
         bl.apply_stencil("cond", bl.Brick(info, st, 0), bl.Brick(info, sb, 0), ids=grid_to_device(lst, dev), coeff=coeff)

@@ -213,7 +213,11 @@ def test_expression_source_generation_and_compilation_without_a_device():
     text = expr_source(s, {"lim": 0.75})
     ops, result = s.program({"lim": 0.75})
     assert text.count(";\n    r") + 1 >= len(ops) and f"return r{result};" in text
-    assert "brklib::brick_apply_fn<2>(" in text and "c[brklib::tap_rel<2>(0, -2, 0)]" in text and "0x1.8p-1" in text and "__builtin_sqrt(" in text
+    # every grid reference of this script moves along one axis: the star staging (ti / tj / ck), not the cube tile
+    assert "brklib::brick_apply_star_fn<2>(" in text and "tj[-16]" in text and "ck[2]" in text and "ti[-1]" in text and "0x1.8p-1" in text
+    assert "__builtin_sqrt(" in text
+    cube = expr_source(load_spec(PRELUDE + NONLINEAR[1].replace("g(i + 1, j, k)", "g(i + 1, j - 2, k)")))
+    assert "brklib::brick_apply_fn<2>(" in cube and "c[brklib::tap_rel<2>(1, -2, 0)]" in cube
     assert expr_source(s, {"lim": 0.75}) == text and expr_source(s, {"lim": 0.5}) != text
     if torch.cuda.is_available():
         return
