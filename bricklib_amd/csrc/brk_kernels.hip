@@ -116,17 +116,18 @@ __global__ __launch_bounds__(64 * WPW) void k_expr(const uint32_t *__restrict__ 
   expr_brick<R>(lds + (threadIdx.x >> 6) * CubeTile<R>::ELEMS, adj, in, out, step, b, pg, threadIdx.x & 63);
 }
 
-// star-shaped stencil given as data, radius 3 or 4 (brk_stencil_apply_taps): one wave per workgroup (27.5 KiB of LDS per wave)
-template <int R>
-__global__ __launch_bounds__(64) void k_star_taps(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
-                                                  size_t step, const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, StarTaps tp) {
-  __shared__ double lds[StarTapTile<R>::ELEMS];
+// star-shaped stencil given as data (brk_stencil_apply_taps): the star staging, WPW waves per workgroup (R = 4: 27.5 KiB of LDS per wave)
+template <int R, int WPW>
+__global__ __launch_bounds__(64 * WPW) void k_star_taps(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,
+                                                        size_t step, const uint32_t *__restrict__ ids, uint32_t first, uint32_t n, StarTaps tp) {
+  __shared__ double lds[WPW * StarTapTile<R>::ELEMS];
   const uint32_t per_xcd = gridDim.x >> 3;
-  const uint32_t slot = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint32_t slot = wg * WPW + (threadIdx.x >> 6);
   if (slot >= n) return;
   const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);
   if (b == BRK_LIST_SKIP) return;
-  star_taps_brick<R>(lds, adj, in, out, step, b, tp, threadIdx.x & 63);
+  star_taps_brick<R>(lds + (threadIdx.x >> 6) * StarTapTile<R>::ELEMS, adj, in, out, step, b, tp, threadIdx.x & 63);
 }
 
 // ================================================================================================================
@@ -855,7 +856,7 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
     return brk_fail(BRK_EINVAL, "1..%d taps with host offset and weight arrays expected (got %u)", kMaxFarTaps, ntaps);
   if (n == 0) return BRK_OK;
   // shape of the table: taps inside the 125-point cube (|offset| <= 2 on every axis) run on the staged (8+2R)^3 tile with the table as a
-  // kernel argument; star-shaped taps (one axis per tap) reach radius 4 on the star staging; cube-shaped taps of radius 3 and 4 (up to
+  // kernel argument; star-shaped taps (one axis per tap) of radius 2..4 on the star staging; cube-shaped taps of radius 3 and 4 (up to
   // 9^3) run on the larger tiles with the table in device memory
   int maxabs = 0;
   bool star = true;
@@ -884,7 +885,9 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
     HIP_TRY(hipGetLastError());
     return BRK_OK;
   }
-  if (maxabs > 2) {
+  // star-shaped tables of radius 2 run on the star staging too (13 taps: 0.649 vs 0.705 ms per 512^3 sweep on the cube tile); radius 1
+  // stays on the cube tile (0.528 vs 0.575)
+  if (maxabs > 2 || (star && maxabs == 2)) {
     StarTaps sp;
     std::memset(&sp, 0, sizeof sp);
     sp.n = (int)ntaps;
@@ -894,8 +897,13 @@ extern "C" int brk_stencil_apply_taps(const uint32_t *adj, const double *in, dou
       sp.off[t] = dk ? dk : (dj ? dj : di);
       sp.w[t] = weights_host[t];
     }
-    brki_note_kernel("k_star_taps<4>");
-    hipLaunchKernelGGL((k_star_taps<4>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, sp);
+    if (maxabs == 2) {
+      brki_note_kernel("k_star_taps<2,2>");
+      hipLaunchKernelGGL((k_star_taps<2, 2>), dim3((((n + 1) / 2 + 7) / 8) * 8), dim3(128), 0, st, adj, in, out, step, ids, first, n, sp);
+    } else {
+      brki_note_kernel("k_star_taps<4,1>");
+      hipLaunchKernelGGL((k_star_taps<4, 1>), dim3(((n + 7) / 8) * 8), dim3(64), 0, st, adj, in, out, step, ids, first, n, sp);
+    }
     HIP_TRY(hipGetLastError());
     return BRK_OK;
   }

@@ -878,13 +878,13 @@ def _taps_cases(oracle):
             # cube-shaped tables beyond the 125-point cube (round 5): all 7^3 / 9^3 taps, sparse off-axis ones, a long star (> 64 taps)
             "cube343": c343, "cube729": c729, "r3-sparse": [c343[q] for q in rng.choice(343, 23, replace=False)] + [((3, -3, 3), 0.5)],
             "r4-sparse": [c729[q] for q in rng.choice(729, 17, replace=False)] + [((-4, 4, -4), -0.25)],
-            "star-r4-long": star(4) * 3,
+            "star-r4-long": star(4) * 3, "star-r2": star(2),
             "star-r3": star(3), "star-r4": star(4), "star-lopsided": [((4, 0, 0), 0.5), ((0, -3, 0), -0.25), ((0, 0, 4), 2.0), ((0, 0, -4), 1.0), ((0, 0, 0), -1.0)],
             "far-i": [((-4, 0, 0), 1.0)], "far-k": [((0, 0, 3), 1.0)]}
 
 
 @pytest.mark.parametrize("case", ["seven", "cube27", "cube125", "lopsided19", "single-shifted", "star-r3", "star-r4", "star-lopsided", "far-i", "far-k",
-                                  "cube343", "cube729", "r3-sparse", "r4-sparse", "star-r4-long"])
+                                  "cube343", "cube729", "r3-sparse", "r4-sparse", "star-r4-long", "star-r2"])
 def test_stencil_given_as_taps(oracle, dev, case):
     """brk_stencil_apply_taps: arbitrary linear stencils up to radius 4 -- inside the 125-point cube, star-shaped, and
     (round 5) cube-shaped to 9^3 taps with the table in device memory (the reference generator takes any script,
@@ -908,6 +908,8 @@ def test_stencil_given_as_taps(oracle, dev, case):
     assert np.abs(so.dat.cpu().numpy() - want).max() <= tol
     if case in ("cube343", "r3-sparse", "cube729", "r4-sparse", "star-r4-long"):
         assert bl.last_kernel() == ("k_taps_far<3,2>" if case in ("cube343", "r3-sparse") else "k_taps_far<4,1>")
+    if case.startswith("star-r") and case != "star-r4-long":
+        assert bl.last_kernel() == ("k_star_taps<2,2>" if case == "star-r2" else "k_star_taps<4,1>")
     if case == "seven":
         sb = bl.BrickStorage.allocate(info.nbricks, 512, dev)
         bl.apply_stencil("7pt", bl.Brick(info, st, 0), bl.Brick(info, sb, 0), ids=grid_to_device(lst, dev), coeff=oracle.coeffs(129, 1))
