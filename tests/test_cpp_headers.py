@@ -262,6 +262,21 @@ def test_example_driver_runs():
 
 
 @pytest.mark.gpu
+def test_cpp_host_runs_a_stencil_given_as_data():
+    """examples/expr_host.cpp: a C++ host without Python builds a register program op by op, runs it interpreted
+    (brk_stencil_apply_expr) and compiled at run time (brk_expr_compile: libhiprtc dlopen'ed by libbrk.so in a process that has no
+    other copy mapped), both bit-identical to a CPU loop over the accessor semantics"""
+    exe = os.path.join(ROOT, "examples", "expr_host")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "expr_host"])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    assert "interpreted (brk_stencil_apply_expr): result match" in out and "compiled at run time (brk_expr_compile): result match" in out, out
+    assert "compiled kernel: k_expr_jit<2,star>" in out, out      # every tap on one axis: the star staging
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(300)
 def test_cpp_weak_driver_exchange_views():
     """examples/weak_hip.cpp: the reference's weak driver shape in C++ -- BrickDecomp + populate_cart, ExchangeView /
