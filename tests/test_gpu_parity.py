@@ -1144,6 +1144,44 @@ def test_random_scripts_interpreted_compiled_and_oracle_agree(oracle, dev, seed)
     assert np.array_equal(got, want) and np.unique(want).size > 1000
 
 
+def test_scripts_over_interleaved_fields(oracle, dev):
+    """the reference's single/ drivers keep bIn and bOut INTERLEAVED in one storage (step 1024, offsets 0 and 512, 3axis.cpp:26-28):
+    stencils given as data -- a radius-3 cube table, an expression interpreted and compiled -- read one field and write the other of the
+    same storage, and leave the input halves untouched"""
+    from bricklib_amd.spec import load_spec
+    from bricklib_amd.stencils import apply_taps
+    shape = (9, 7, 6)
+    grid, info = bl.init_grid(shape, dev)
+    ids = np.ascontiguousarray(grid.reshape(6, 7, 9)[1:-1, 1:-1, 1:-1]).reshape(-1)
+    ids_dev = grid_to_device(ids, dev)
+    rng = np.random.default_rng(11)
+    taps = [((int(a), int(b), int(c)), float(w)) for a, b, c, w in zip(*(rng.integers(-3, 4, 40) for _ in range(3)), rng.uniform(-1, 1, 40))] + [((3, -3, 2), 0.5)]
+    spec = load_spec(EXPR_SCRIPTS["limiter"])
+    consts = {"cfl": 0.3}
+    ck = bl.CompiledExpr(spec, consts)
+    runs = {"taps": lambda A, B: apply_taps(taps, A, B, ids=ids_dev), "interpreted": lambda A, B: bl.apply_expr(spec, A, B, ids=ids_dev, constants=consts),
+            "compiled": lambda A, B: ck.apply(A, B, ids=ids_dev)}
+    for name, run in runs.items():
+        st = bl.BrickStorage.allocate(info.nbricks, 1024, dev)
+        st.dat.uniform_(-0.5, 0.5)
+        st.dat.view(-1, 1024)[:, 512:] = 0
+        before = st.dat.view(-1, 1024)[:, :512].clone()
+        run(bl.Brick(info, st, 0), bl.Brick(info, st, 512))
+        assert torch.equal(st.dat.view(-1, 1024)[:, :512], before), name
+        hin = np.ascontiguousarray(before.cpu().numpy()).reshape(-1)
+        want = np.zeros_like(hin)
+        if name == "taps":
+            oracle.brick_taps(info.adj_host, hin, want, 512, ids, taps)
+        else:
+            oracle.brick_expr(spec, info.adj_host, hin, want, 512, ids, consts)
+        got = st.dat.cpu().numpy().reshape(-1, 1024)[:, 512:]
+        if name == "taps":
+            assert np.abs(got - want.reshape(-1, 512)).max() <= TOL and np.abs(want).max() > 0.1
+        else:
+            assert np.array_equal(got, want.reshape(-1, 512)), name
+    ck.release()
+
+
 def test_expression_argument_checks(dev):
     """a program is checked before anything is launched: unknown codes, registers out of range or read before written, taps
     outside the 125-point cube, too many operations"""
