@@ -931,7 +931,7 @@ extern "C" int brk_stencil_apply_expr(const uint32_t *adj, const double *in, dou
   if (n == 0) return ops_host && nops ? BRK_OK : brk_fail(BRK_EINVAL, "1..%d ops expected (got %u)", kMaxExprOps, nops);
   static_assert(kMaxExprOps == BRK_EXPR_MAX_OPS && kMaxExprRegs == BRK_EXPR_MAX_REGS && (int)EX_SEL == (int)BRK_EX_SEL, "brk_internal.h / brk.h disagree with brick-device.h");
   int radius = 1;
-  if (int rc = brki_expr_check(ops_host, nops, result_reg, &radius)) return rc;
+  if (int rc = brki_expr_check(ops_host, nops, BRK_EXPR_MAX_OPS, result_reg, &radius)) return rc;
   ExprProg pg;
   std::memset(&pg, 0, sizeof pg);
   pg.n = (int)nops, pg.radius = radius, pg.result = (int)result_reg;

@@ -176,7 +176,7 @@ def _resolver(constants):
 
 EX = {"tap": 0, "const": 1, "add": 2, "sub": 3, "mul": 4, "div": 5, "neg": 6, "max": 7, "min": 8, "abs": 9, "sqrt": 10, "gt": 11, "ge": 12,
       "lt": 13, "le": 14, "eq": 15, "ne": 16, "if": 17}       # BRK_EX_* of include/brk.h
-MAX_REGS, MAX_OPS = 16, 120
+MAX_REGS, MAX_OPS, MAX_OPS_COMPILED = 16, 120, 512     # interpreter: the program travels as a kernel argument; compiled: as text
 
 
 class Spec:
@@ -249,13 +249,16 @@ class Spec:
                 return name
         return None
 
-    def program(self, constants=None, as_c=False):
+    def program(self, constants=None, as_c=False, max_ops=MAX_OPS):
         """(ops, result register): the expression as a register program for brk_stencil_apply_expr -- ops are dicts
         {code, dst, a, b, c, offset, imm}; at most 16 registers live at a time (a sub-expression used several times, like `calc` in
         cond.py's If(calc > 0, calc, -calc), is computed once and kept).  constants: as for taps(); as_c: `imm` of a ConstRef stays its
         C text (what tools/brkscatter writes into a driver, where `coeff[3]` is an lvalue of the kernel)."""
         if self.radius > 4:
             raise ValueError(f"radius {self.radius}: stencils given as data reach |offset| <= 4 per axis")
+        import sys
+        if sys.getrecursionlimit() < 20000:      # a sum of hundreds of taps is a tree that deep
+            sys.setrecursionlimit(20000)
         value = _resolver(constants)
         uses = {}
 
@@ -309,14 +312,17 @@ class Spec:
             return dst
 
         result = gen(self.expr)
-        if len(ops) > MAX_OPS:
-            raise ValueError(f"the expression compiles to {len(ops)} operations (at most {MAX_OPS})")
+        if len(ops) > max_ops:
+            raise ValueError(f"the expression compiles to {len(ops)} operations (at most {max_ops})")
         return ops, result
 
     def evaluate(self, tap_value, constants=None):
         """numpy evaluation of the expression: tap_value(offset) -> array of in[p + offset] over the cells wanted (the checker's side
         of the expression path: oracle.brick_expr feeds it with the accessor's values)"""
+        import sys
         import numpy as np
+        if sys.getrecursionlimit() < 20000:
+            sys.setrecursionlimit(20000)
         value = _resolver(constants)
         memo = {}
 

@@ -56,9 +56,10 @@ def apply_stencil(stencil, bIn, bOut, ids=None, brick_range=None, box=None, coef
                                              _stream(stream)))
 
 
-def _expr_table(spec, constants):
+def _expr_table(spec, constants, max_ops=None):
     from ._lib import ExprOp
-    ops, result = spec.program(constants)
+    from .spec import MAX_OPS
+    ops, result = spec.program(constants, max_ops=max_ops or MAX_OPS)
     tab = (ExprOp * len(ops))()
     for q, o in enumerate(ops):
         tab[q].code, tab[q].dst, tab[q].a, tab[q].b, tab[q].c, tab[q].imm = o["code"], o["dst"], o["a"], o["b"], o["c"], float(o["imm"])
@@ -74,7 +75,8 @@ class CompiledExpr:
 
     def __init__(self, spec, constants=None):
         import ctypes as C
-        tab, n, result = _expr_table(spec, constants)
+        from .spec import MAX_OPS_COMPILED
+        tab, n, result = _expr_table(spec, constants, MAX_OPS_COMPILED)
         self._h = C.c_void_p()
         check(lib.brk_expr_compile(tab, n, result, C.byref(self._h)))
 
@@ -105,7 +107,8 @@ class CompiledExpr:
 def expr_source(spec, constants=None):
     """the translation unit brk_expr_compile would compile for this script (no compiler, no device needed)"""
     import ctypes as C
-    tab, n, result = _expr_table(spec, constants)
+    from .spec import MAX_OPS_COMPILED
+    tab, n, result = _expr_table(spec, constants, MAX_OPS_COMPILED)
     need = C.c_size_t()
     check(lib.brk_expr_source(tab, n, result, None, 0, C.byref(need)))
     buf = C.create_string_buffer(need.value)

@@ -192,7 +192,8 @@ int brk_stencil_apply_expr(const uint32_t *adj_dev, const double *in_dev, double
  * (codegen/vecscatter); a host that holds the script as data gets that here: brk_expr_compile writes the operations out as
  * straight-line HIP over the staged tile (the text tools/brkscatter emits for a brick(...) line; brk_expr_source returns it without
  * compiling) and compiles it with hiprtc for the current device -- about a second, once per distinct program and device (a second
- * compile of the same program returns the same kernel).  brk_expr_apply then runs at the speed of the generic tap path instead of the
+ * compile of the same program returns the same kernel; up to 512 operations -- linear sums of many taps belong to
+ * brk_stencil_apply_taps: 125 taps as straight-line code run slower than the tap table).  brk_expr_apply then runs at the speed of the generic tap path instead of the
  * interpreter's.  Same operations, one fp64 rounding each (-ffp-contract=off): the same numbers as brk_stencil_apply_expr.
  * BRK_ENODEV: libhiprtc could not be loaded, or there is no device.  brk_finalize unloads the modules; a kernel used after that is
  * refused until its program is compiled again.  brk_expr_release when done (NULL is a no-op). */

@@ -254,3 +254,18 @@ def test_random_scripts_compile_to_equivalent_programs(steps):
             assert f"return r{result};" in expr_source(s, {"cA": 0.3})
         compiled += 1
     assert compiled >= 30, (compiled, refused)
+
+
+def test_compiled_form_takes_longer_programs_than_the_interpreter():
+    """the interpreter's program is a kernel argument (120 operations); the compiled form is text (512)"""
+    from bricklib_amd.spec import MAX_OPS, MAX_OPS_COMPILED
+    from bricklib_amd.stencils import expr_source
+    body = "g = Grid('a', 3); h = Grid('b', 3)\nf = Func('max', 2)\ne = g(i, j, k)\n" + \
+        "for q in range(%d):\n    e = f(e, g(i + q %% 3 - 1, j, k)) * g(i, j + q %% 5 - 2, k)\n" + "h(i, j, k).assign(e)\nSTENCIL = [h]"
+    s = load_spec(PRELUDE + body % 70)
+    with pytest.raises(ValueError, match="at most %d" % MAX_OPS):
+        s.program()
+    ops, _ = s.program(max_ops=MAX_OPS_COMPILED)
+    assert MAX_OPS < len(ops) <= MAX_OPS_COMPILED and "brick_apply_fn<2>" in expr_source(s)
+    with pytest.raises(ValueError, match="at most %d" % MAX_OPS_COMPILED):
+        load_spec(PRELUDE + body % 200).program(max_ops=MAX_OPS_COMPILED)

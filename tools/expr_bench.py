@@ -86,6 +86,14 @@ def main():
     for r in (2, 3, 4):
         cube = [((di, dj, dk), 1.0 / (1 + abs(di) + abs(dj) + abs(dk))) for dk, dj, di in itertools.product(range(-r, r + 1), repeat=3)]
         timed(f"all {len(cube)} taps of the radius-{r} cube (tap path)", lambda: bl.apply_taps(cube, A, B, ids=ids))
+    # linear scripts with many taps, compiled (straight-line code, weights as literals) against the table paths
+    for r in (2,):       # (radius 3: 1 371 operations, beyond the compiled form's limit -- it spilled: 87 ms)
+        text = HEAD + "acc = None\nfor dk in range(-%d, %d):\n  for dj in range(-%d, %d):\n    for di in range(-%d, %d):\n      t = (1.0 / (1 + abs(di) + abs(dj) + abs(dk))) * u(i + di, j + dj, k + dk)\n      acc = t if acc is None else acc + t\nv(i, j, k).assign(acc)\nSTENCIL = [v]\n" % (r, r + 1, r, r + 1, r, r + 1)
+        sp = load_spec(text)
+        t0 = time.time()
+        cc = bl.CompiledExpr(sp)
+        print(f"  (brk_expr_compile, {(2 * r + 1) ** 3} taps: {time.time() - t0:.2f} s)")
+        timed(f"all {(2 * r + 1) ** 3} taps of the radius-{r} cube, compiled", lambda: cc.apply(A, B, ids=ids))
     far = load_spec(HEAD + """
 hi = Func("max", 2)
 v(i, j, k).assign(hi(u(i + 3, j - 3, k + 1), u(i - 2, j + 3, k - 3)) * u(i, j, k) - u(i - 3, j, k))
