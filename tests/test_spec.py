@@ -266,6 +266,6 @@ def test_compiled_form_takes_longer_programs_than_the_interpreter():
     with pytest.raises(ValueError, match="at most %d" % MAX_OPS):
         s.program()
     ops, _ = s.program(max_ops=MAX_OPS_COMPILED)
-    assert MAX_OPS < len(ops) <= MAX_OPS_COMPILED and "brick_apply_fn<2>" in expr_source(s)
+    assert MAX_OPS < len(ops) <= MAX_OPS_COMPILED and "brick_apply_star_fn<2>" in expr_source(s)
     with pytest.raises(ValueError, match="at most %d" % MAX_OPS_COMPILED):
         load_spec(PRELUDE + body % 200).program(max_ops=MAX_OPS_COMPILED)
