@@ -3,8 +3,8 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (BRK_7PT_COEFF, BRK_27PT_COEFF, BRK_MPI7, BRK_MPI13, BRK_MPI25, BRK_MPI125, BRK_SWEEP_KPAIRED, BRK_SWEEP_REVERSE, check,
-                   lib)
+from ._lib import (BRK_7PT_COEFF, BRK_27PT_COEFF, BRK_MPI7, BRK_MPI13, BRK_MPI25, BRK_MPI125, BRK_SWEEP_KPAIRED, BRK_SWEEP_REVERSE, BrkError,
+                   check, lib)
 from .brick import _ptr, _stream
 
 # name -> id; names follow the reference's stencil scripts (stencils/*.py) and drivers
@@ -116,12 +116,29 @@ def expr_source(spec, constants=None):
     return buf.value.decode()
 
 
-def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None):
-    """A stencil script as an expression, INTERPRETED (brk_stencil_apply_expr): `spec` = bricklib_amd.spec.load_spec(...) of ANY script
-    up to radius 4 -- Func("max" / "min" / "abs" / "sqrt"), comparisons, If, products of grid references included (what the
-    reference's generator accepts; stencils/cond.py is made of these).  constants: values of the script's ConstRef names.  No compiler
-    involved and about 10x slower than CompiledExpr(spec, constants).apply(...), which runs the same operations as generated code;
-    linear scripts are better served by apply_taps / the built-in stencils."""
+def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None, interpret=False):
+    """A stencil script as an expression: `spec` = bricklib_amd.spec.load_spec(...) of ANY script up to radius 4 -- Func("max" / "min" /
+    "abs" / "sqrt"), comparisons, If, products of grid references included (what the reference's generator accepts; stencils/cond.py is
+    made of these).  constants: values of the script's ConstRef names.
+    Default: the script is COMPILED at run time on first use (CompiledExpr: hiprtc, about a second, kept on `spec` per set of constants)
+    and runs as generated code.  interpret=True: brk_stencil_apply_expr, the same operations interpreted -- no compiler involved, about
+    10x slower, programs up to 120 operations.  Both give the same numbers bit for bit.  Linear scripts are better served by apply_taps
+    / the built-in stencils."""
+    if not interpret:
+        from .spec import MAX_OPS_COMPILED
+        tab, n, result = _expr_table(spec, constants, MAX_OPS_COMPILED)
+        cache = spec.__dict__.setdefault("_compiled", {})
+        key = (bytes(tab), result)
+        ck = cache.get(key)
+        if ck is None or not ck._h:
+            ck = cache[key] = CompiledExpr(spec, constants)
+        try:
+            return ck.apply(bIn, bOut, ids=ids, brick_range=brick_range, stream=stream)
+        except BrkError as e:
+            if "compile the program again" not in str(e):
+                raise
+        ck = cache[key] = CompiledExpr(spec, constants)       # unloaded by finalize(): the same kernel, loaded again
+        return ck.apply(bIn, bOut, ids=ids, brick_range=brick_range, stream=stream)
     tab, n, result = _expr_table(spec, constants)
     adj = bIn.bInfo.adj
     if ids is not None:

@@ -1006,7 +1006,7 @@ def test_stencil_given_as_expression(oracle, dev, case):
     so = bl.BrickStorage.allocate(info.nbricks, 512, dev)
     lst = tiled(grid.reshape(6, 7, 9)[1:-1, 1:-1, 1:-1])
     assert (lst == LIST_SKIP).any()
-    bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, so, 0), ids=grid_to_device(lst, dev), constants=consts)
+    bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, so, 0), ids=grid_to_device(lst, dev), constants=consts, interpret=True)
     assert bl.last_kernel() == {1: "k_expr<1,4>", 2: "k_expr<2,4>", 3: "k_expr<3,2>", 4: "k_expr<4,1>"}[spec.radius]
     hin = st.dat.cpu().numpy()
     want = np.zeros_like(hin)
@@ -1030,7 +1030,7 @@ def test_stencil_given_as_expression(oracle, dev, case):
     A, B = dinfo.allocate(512, dev), dinfo.allocate(512, dev)
     A.dat.uniform_(-0.5, 0.5)
     A.dat[:512] = 0
-    bl.apply_expr(spec, bl.Brick(dinfo, A, 0), bl.Brick(dinfo, B, 0), brick_range=(1, d.sep_pos[2]), constants=consts)
+    bl.apply_expr(spec, bl.Brick(dinfo, A, 0), bl.Brick(dinfo, B, 0), brick_range=(1, d.sep_pos[2]), constants=consts, interpret=True)
     hin2 = A.dat.cpu().numpy()
     want2 = np.zeros_like(hin2)
     oracle.brick_expr(spec, d.adj, hin2, want2, 512, np.arange(1, d.sep_pos[2], dtype=np.uint32), consts)
@@ -1059,8 +1059,14 @@ def test_compiled_expression_lifecycle(dev):
     a.apply(bl.Brick(info, st, 0), bl.Brick(info, s1, 0))
     c.apply(bl.Brick(info, st, 0), bl.Brick(info, s2, 0))
     assert not torch.equal(s1.dat, s2.dat)
-    bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, s2, 0), constants={"cfl": 0.3})
-    assert torch.equal(s1.dat, s2.dat)
+    bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, s2, 0), constants={"cfl": 0.3}, interpret=True)
+    assert torch.equal(s1.dat, s2.dat) and bl.last_kernel() == "k_expr<2,4>"
+    # apply_expr's default: compiled on first use, kept on the spec per set of constants
+    for cfl in (0.3, 0.3, 0.25):
+        s2.dat.zero_()
+        bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, s2, 0), constants={"cfl": cfl})
+        assert bl.last_kernel() == "k_expr_jit<2>" and torch.equal(s1.dat, s2.dat) == (cfl == 0.3)
+    assert len(spec._compiled) == 2 and {k._h.value for k in spec._compiled.values()} == {a._h.value, c._h.value}
     with pytest.raises(BrkError):
         a.apply(bl.Brick(info, st, 0), bl.Brick(info, st, 0))          # in == out
     bl.finalize()
@@ -1072,7 +1078,7 @@ def test_compiled_expression_lifecycle(dev):
     a.apply(bl.Brick(info, st, 0), bl.Brick(info, s2, 0))
     assert torch.equal(s1.dat, s2.dat)
     handle = c._h.value
-    for k in (a, b, c, again):
+    for k in (a, b, c, again, *spec._compiled.values()):
         k.release()
     assert lib.brk_expr_release(C.c_void_p(handle)) != 0               # gone already
 
@@ -1098,7 +1104,7 @@ def test_scripts_at_baseline_size_512(oracle, dev):
     ck.apply(B(x), B(a), ids=ids_dev)
     bl.apply_stencil("cond", B(x), B(b), ids=ids_dev, coeff=coeff)
     assert (a.dat - b.dat).abs().max().item() <= TOL and a.dat.abs().max().item() > 0.1
-    bl.apply_expr(spec, B(x), B(c), ids=ids_dev, constants={"coeff": coeff})
+    bl.apply_expr(spec, B(x), B(c), ids=ids_dev, constants={"coeff": coeff}, interpret=True)
     assert torch.equal(a.dat, c.dat)
     real = ids[ids != 0xFFFFFFFF]
     mask = torch.ones(info.nbricks, dtype=torch.bool, device=dev)
@@ -1132,7 +1138,7 @@ def test_random_scripts_interpreted_compiled_and_oracle_agree(oracle, dev, seed)
     A.dat.uniform_(-0.5, 0.5)
     A.dat[:512] = 0
     rng = (1, d.sep_pos[2])
-    bl.apply_expr(spec, bl.Brick(dinfo, A, 0), bl.Brick(dinfo, B, 0), brick_range=rng, constants=consts)
+    bl.apply_expr(spec, bl.Brick(dinfo, A, 0), bl.Brick(dinfo, B, 0), brick_range=rng, constants=consts, interpret=True)
     ck = bl.CompiledExpr(spec, consts)
     ck.apply(bl.Brick(dinfo, A, 0), bl.Brick(dinfo, C, 0), brick_range=rng)
     ck.release()
@@ -1159,7 +1165,7 @@ def test_scripts_over_interleaved_fields(oracle, dev):
     spec = load_spec(EXPR_SCRIPTS["limiter"])
     consts = {"cfl": 0.3}
     ck = bl.CompiledExpr(spec, consts)
-    runs = {"taps": lambda A, B: apply_taps(taps, A, B, ids=ids_dev), "interpreted": lambda A, B: bl.apply_expr(spec, A, B, ids=ids_dev, constants=consts),
+    runs = {"taps": lambda A, B: apply_taps(taps, A, B, ids=ids_dev), "interpreted": lambda A, B: bl.apply_expr(spec, A, B, ids=ids_dev, constants=consts, interpret=True),
             "compiled": lambda A, B: ck.apply(A, B, ids=ids_dev)}
     for name, run in runs.items():
         st = bl.BrickStorage.allocate(info.nbricks, 1024, dev)
@@ -1207,7 +1213,7 @@ def test_expression_argument_checks(dev):
     from bricklib_amd.spec import load_spec
     with pytest.raises(BrkError):       # in == out
         bl.apply_expr(load_spec(EXPR_SCRIPTS["cond"]), bl.Brick(info, st, 0), bl.Brick(info, st, 0), brick_range=(0, 1),
-                      constants={"coeff": [0.1] * 7})
+                      constants={"coeff": [0.1] * 7}, interpret=True)
 
 
 def test_taps_argument_checks(dev):

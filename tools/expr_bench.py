@@ -62,7 +62,7 @@ def main():
         print(f"{name:44s} {ms:7.3f} ms/sweep  {512 ** 3 / ms / 1e6:7.1f} GStencil/s  {bl.last_kernel()}", flush=True)
 
     timed("cond.py tuned kernel (BRK_COND7)", lambda: bl.apply_stencil("cond", A, B, ids=ids, coeff=coeff + [0.0] * 122))
-    timed("cond-shaped script, interpreted", lambda: bl.apply_expr(cond, A, B, ids=ids, constants={"coeff": coeff}))
+    timed("cond-shaped script, interpreted", lambda: bl.apply_expr(cond, A, B, ids=ids, constants={"coeff": coeff}, interpret=True))
     import time
     t0 = time.time()
     ck = bl.CompiledExpr(cond, {"coeff": coeff})
@@ -71,14 +71,14 @@ def main():
     lin = load_spec(COND.replace('pos(u(i + di, j + dj, k + dk), 0.0)', 'u(i + di, j + dj, k + dk)').replace("If(total > 0, total, -total)", "total"))
     taps = lin.taps({"coeff": coeff})
     timed("same 7 taps, linear tap path (k_taps)", lambda: bl.apply_taps(taps, A, B, ids=ids))
-    timed("same 7 taps, linear, interpreted", lambda: bl.apply_expr(lin, A, B, ids=ids, constants={"coeff": coeff}))
+    timed("same 7 taps, linear, interpreted", lambda: bl.apply_expr(lin, A, B, ids=ids, constants={"coeff": coeff}, interpret=True))
     cl = bl.CompiledExpr(lin, {"coeff": coeff})
     timed("same 7 taps, linear, compiled", lambda: cl.apply(A, B, ids=ids))
-    timed("minmod.py (3 limited slopes), interpreted", lambda: bl.apply_expr(minmod, A, B, ids=ids, constants={"coeff": coeff}))
+    timed("minmod.py (3 limited slopes), interpreted", lambda: bl.apply_expr(minmod, A, B, ids=ids, constants={"coeff": coeff}, interpret=True))
     cm = bl.CompiledExpr(minmod, {"coeff": coeff})
     timed("minmod.py (3 limited slopes), compiled", lambda: cm.apply(A, B, ids=ids))
     lim = load_spec(LIMITER)
-    timed("radius-2 limiter, interpreted", lambda: bl.apply_expr(lim, A, B, ids=ids))
+    timed("radius-2 limiter, interpreted", lambda: bl.apply_expr(lim, A, B, ids=ids, interpret=True))
     c2 = bl.CompiledExpr(lim)
     timed("radius-2 limiter, compiled", lambda: c2.apply(A, B, ids=ids))
     # beyond the 125-point cube: (8 + 2R)^3 tiles, 2 / 1 waves per workgroup
@@ -99,7 +99,7 @@ hi = Func("max", 2)
 v(i, j, k).assign(hi(u(i + 3, j - 3, k + 1), u(i - 2, j + 3, k - 3)) * u(i, j, k) - u(i - 3, j, k))
 STENCIL = [v]
 """)
-    timed("radius-3 off-axis max/product, interpreted", lambda: bl.apply_expr(far, A, B, ids=ids))
+    timed("radius-3 off-axis max/product, interpreted", lambda: bl.apply_expr(far, A, B, ids=ids, interpret=True))
     c3 = bl.CompiledExpr(far)
     timed("radius-3 off-axis max/product, compiled", lambda: c3.apply(A, B, ids=ids))
     far4 = load_spec(HEAD + """
