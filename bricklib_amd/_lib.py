@@ -159,6 +159,7 @@ def _load():
     L.brk_expr_source.argtypes = [C.POINTER(ExprOp), C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.brk_expr_kernel_source.argtypes = [vp]
     L.brk_expr_kernel_source.restype = C.c_char_p
+    L.brk_expr_kernel_from_disk.argtypes = [vp]
     L.brk_finalize.argtypes = []
     L.brk_last_kernel.restype = C.c_char_p
     L.brk_last_kernel.argtypes = []
@@ -171,7 +172,7 @@ lib = _load()
 ABI_SYMBOLS = [
     "brk_last_error", "brk_abi_version", "brk_stencil_radius", "brk_stencil_ncoeff", "brk_stencil_iters",
     "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_stencil_apply_list_kpaired", "brk_stencil_apply_box", "brk_stencil_apply_range_ex", "brk_stencil_apply_list_ex", "brk_stencil_apply_box_ex", "brk_stencil_apply_taps", "brk_stencil_apply_expr", "brk_expr_compile", "brk_expr_apply", "brk_expr_release", "brk_expr_source",
-               "brk_expr_kernel_source", "brk_link_copy", "brk_array_to_brick",
+               "brk_expr_kernel_source", "brk_expr_kernel_from_disk", "brk_link_copy", "brk_array_to_brick",
     "brk_brick_to_array", "brk_compare_brick", "brk_init_grid", "brk_decomp_build", "brk_decomp_free",
     "brk_decomp_nbricks", "brk_decomp_grid_size", "brk_decomp_tdims", "brk_decomp_sep_pos", "brk_decomp_grid",
     "brk_decomp_adj", "brk_decomp_nruns", "brk_decomp_ghost", "brk_decomp_skin", "brk_decomp_nskin",

@@ -84,6 +84,11 @@ class CompiledExpr:
     def source(self):
         return lib.brk_expr_kernel_source(self._h).decode()
 
+    @property
+    def from_disk(self):
+        """True when the code object came out of BRK_JIT_CACHE_DIR instead of the compiler"""
+        return bool(lib.brk_expr_kernel_from_disk(self._h))
+
     def apply(self, bIn, bOut, ids=None, brick_range=None, stream=None):
         adj = bIn.bInfo.adj
         if ids is not None:

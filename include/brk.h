@@ -66,7 +66,8 @@ const char *brk_last_error(void);
  * 1005: brk_stencil_apply_{range,list,box}_ex with BRK_SWEEP_* flags; 1006: brk_comm_library, the development knob
  * brk_set_variant is no longer part of the ABI; 1007: brk_storage_alloc / brk_storage_free / brk_placement_probe;
  * 1008: brk_finalize, brk_last_kernel; 1009: brk_storage_alloc_ex; 1010: brk_stencil_apply_expr;
- * 1011: brk_expr_compile / brk_expr_apply / brk_expr_release / brk_expr_source / brk_expr_kernel_source) */
+ * 1011: brk_expr_compile / brk_expr_apply / brk_expr_release / brk_expr_source / brk_expr_kernel_source;
+ * 1012: brk_expr_kernel_from_disk (BRK_JIT_CACHE_DIR)) */
 int brk_abi_version(void);
 /* Orderly end of the library's use of the GPU before a process leaves main(): waits for everything enqueued on the current device
  * and releases, on the CALLING thread, what the library itself holds there (box id lists and their events, derived tables of
@@ -205,6 +206,9 @@ int brk_expr_release(brk_expr_kernel *k);
 /* the generated translation unit: of a program (buf may be NULL; *need = bytes incl. the terminator) / of a compiled kernel */
 int brk_expr_source(const brk_expr_op *ops_host, uint32_t nops, uint32_t result_reg, char *buf, size_t cap, size_t *need);
 const char *brk_expr_kernel_source(const brk_expr_kernel *k);
+/* BRK_JIT_CACHE_DIR=<directory> (ABI 1012): code objects are kept there across processes, named after everything they depend on
+ * (generated text, the embedded device headers, target); brk_expr_compile then loads instead of compiling.  1 = this kernel was. */
+int brk_expr_kernel_from_disk(const brk_expr_kernel *k);
 /* Development builds of the library (make -C bricklib_amd/csrc DEV=1 or VARIANTS=1) additionally export the experiment knobs
  * used by tools/kbench (kernel variant selection, LDS padding, diagnostic modes), looked up with dlsym.  They are not declared
  * here and the default libbrk.so does not contain them: not part of this ABI. */

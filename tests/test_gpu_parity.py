@@ -1,5 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the pinned CPU oracle.  Needs an MI355X."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from bricklib_amd.drivers import weak_cycle
 from oracle.oracle import ST_7PT_COEFF, ST_27PT_COEFF, ST_MPI7, ST_MPI13, ST_MPI25, ST_MPI125
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _set_variant_or_skip(lib, sid, variant):
@@ -1186,6 +1188,48 @@ def test_scripts_over_interleaved_fields(oracle, dev):
         else:
             assert np.array_equal(got, want.reshape(-1, 512)), name
     ck.release()
+
+
+def test_compiled_kernels_are_kept_on_disk_across_processes(tmp_path):
+    """BRK_JIT_CACHE_DIR: the first process compiles a script and leaves the code object in the directory, the second one loads it
+    (brk_expr_kernel_from_disk) and computes the same field; a file that is not a code object is ignored and replaced"""
+    import subprocess
+    import sys
+    prog = """
+import sys, torch
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import bricklib_amd as bl
+from bricklib_amd.spec import load_spec
+from random_scripts import random_script
+dev = torch.device("cuda:0")
+spec = load_spec(random_script(4, radius=2, steps=20))
+ck = bl.CompiledExpr(spec, {"cA": 0.3})
+grid, info = bl.init_grid((4, 4, 4), dev)
+a, b = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(2))
+torch.manual_seed(3)
+a.dat.copy_(torch.rand(a.dat.shape, dtype=torch.float64) - 0.5)
+ck.apply(bl.Brick(info, a, 0), bl.Brick(info, b, 0))
+print("from_disk", int(ck.from_disk), "checksum", repr(b.dat.sum().item()))
+ck.release()
+bl.finalize()
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, BRK_JIT_CACHE_DIR=str(tmp_path))
+
+    def run():
+        r = subprocess.run([sys.executable, "-c", prog], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        out = r.stdout.decode()
+        assert r.returncode == 0, out[-2000:]
+        line = [l for l in out.splitlines() if l.startswith("from_disk")][-1].split()
+        return int(line[1]), line[3]
+    first = run()
+    files = [f for f in os.listdir(tmp_path) if f.startswith("brk_expr_") and f.endswith(".co")]
+    assert first[0] == 0 and len(files) == 1 and os.path.getsize(tmp_path / files[0]) > 4000
+    second = run()
+    assert second == (1, first[1])
+    (tmp_path / files[0]).write_bytes(b"not a code object")
+    third = run()
+    assert third == (0, first[1]) and os.path.getsize(tmp_path / files[0]) > 4000
 
 
 def test_expression_argument_checks(dev):
