@@ -97,6 +97,15 @@ __global__ void blur343_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, B
   brick("blur343.py", VSVEC, (BDIM), (VFOLD), b);
 }
 
+// ... and a star-shaped one that is none of the built-in stars: examples/aniso7.py, one weight per direction (star staging)
+__global__ void aniso7_brick(unsigned (*grid)[STRIDEB][STRIDEB], Brick3D bIn, Brick3D bOut, bElem *coeff) {
+  long tk = GB + hipBlockIdx_z;
+  long tj = GB + hipBlockIdx_y;
+  long ti = GB + hipBlockIdx_x;
+  unsigned b = grid[tk][tj][ti];
+  brick("aniso7.py", VSVEC, (BDIM), (VFOLD), b);
+}
+
 static int run() {
   bElem *coeff = (bElem *)malloc(COEFF_SIZE * sizeof(bElem));
   {
@@ -270,6 +279,21 @@ static int run() {
     hipLaunchKernelGGL(blur343_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
     gpuCheck(hipDeviceSynchronize());
     check("brick() blur343 kernel (radius-3 cube script, 343 taps)");
+  }
+  // (8) a user-written star with one weight per direction (aniso7.py): the star staging, radius 1
+  {
+#pragma omp parallel for collapse(2)
+    for (long k = PADDING + GZ; k < PADDING + GZ + N; ++k)
+      for (long j = PADDING + GZ; j < PADDING + GZ + N; ++j)
+        for (long i = PADDING + GZ; i < PADDING + GZ + N; ++i)
+          arr_out[k][j][i] = coeff[0] * arr_in[k][j][i] + coeff[1] * arr_in[k][j][i + 1] + 0.5 * coeff[2] * arr_in[k][j][i - 1] +
+                             coeff[3] * arr_in[k][j + 1][i] - coeff[4] * arr_in[k][j - 1][i] + coeff[5] * arr_in[k + 1][j][i] +
+                             0.25 * coeff[6] * arr_in[k - 1][j][i];
+    Brick3D dIn(binfo_dev, bstorage_dev, 0), dOut(binfo_dev, bstorage_dev, bsize);
+    dim3 block(NB, NB, NB), thread(64);
+    hipLaunchKernelGGL(aniso7_brick, block, thread, 0, 0, grid, dIn, dOut, coeff_dev);
+    gpuCheck(hipDeviceSynchronize());
+    check("brick() aniso7 kernel (star-shaped script, star staging)");
   }
   return 0;
 }

@@ -257,6 +257,7 @@ def test_example_driver_runs():
     assert "brick() star37 kernel (radius-3 star script read as data): result match" in out, out   # beyond the 125-point cube: star path
     assert "brick() minmod kernel (non-linear script, generated straight-line code): result match" in out, out  # If / Func / products
     assert "brick() blur343 kernel (radius-3 cube script, 343 taps): result match" in out, out   # cube-shaped beyond radius 2
+    assert "brick() aniso7 kernel (star-shaped script, star staging): result match" in out, out   # star of radius 1, not a built-in
     out2 = subprocess.run([os.path.join(ROOT, "examples", "dev_shl_check")], check=True, stdout=subprocess.PIPE).stdout.decode()
     assert "dev_shl: ok" in out2, out2
 
@@ -417,7 +418,7 @@ def test_cmake_vstarget_hook_and_library_names(tmp_path):
     r = subprocess.run(["cmake", "--build", str(b)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
-    assert "[VS][single_hip_cmake]" in out and "6 brick(...) and 0 tile(...) call(s) rewritten" in out
+    assert "[VS][single_hip_cmake]" in out and "7 brick(...) and 0 tile(...) call(s) rewritten" in out
     assert (b / "single_hip_cmake").exists()
     txt = open(os.path.join(ROOT, "CMakeLists.txt")).read()
     for name in ("brick", "brick-mpi", "brickhelper"):
