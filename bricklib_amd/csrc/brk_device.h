@@ -7,6 +7,7 @@
 
 #include "brick-device.h"
 #include "brk_internal.h"
+#include "brk_sbase.h"
 
 namespace brklib {
 
@@ -28,19 +29,6 @@ constexpr int kWG = 64 * kWavesPerWG;
     hipError_t e_ = (expr);                                                                       \
     if (e_ != hipSuccess) return brk_fail(BRK_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
-
-// Global-address-space pointers whose (wave-uniform) value is hidden from the optimiser: accesses through them are
-// emitted as global_load/global_store with an SGPR base and a 32-bit per-lane offset.  Without this hipcc folds
-// base+lane into 64-bit VGPR addresses (two VGPRs and two VALU ops per access).  The address space must be kept
-// explicit: a generic pointer after the asm would turn the accesses into flat_* instructions, which force
-// vmcnt(0)/lgkmcnt(0) waits.
-typedef const __attribute__((address_space(1))) double *gcptr;
-typedef __attribute__((address_space(1))) double *gptr;
-__device__ __forceinline__ gcptr sbase(const double *p) {
-  gcptr g = (gcptr)p;
-  asm volatile("" : "+s"(g));
-  return g;
-}
 
 // Launchers of the specialised 7-point kernels (brk_star7.hip).  variant: 2 = one brick per wave, every face gathered;
 // 5 / 6 = workgroups of 8 / 4 waves sharing i-faces through LDS.

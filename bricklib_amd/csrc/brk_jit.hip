@@ -23,10 +23,11 @@
 #include <mutex>
 #include <string>
 
+#include "brick-device.h" // brklib::Coeffs (an argument of k_s7_wg)
 #include "brk_internal.h"
 
 namespace {
-#include "brk_jit_headers.inc" // kJitDeviceHeader (brick-device.h), kJitAbiHeader (brk.h)
+#include "brk_jit_headers.inc" // kJitDeviceHeader (brick-device.h), kJitAbiHeader (brk.h), kJitSbaseHeader (brk_sbase.h), kJitStar7Header (brk_star7_kernel.h)
 
 struct Rtc {
   void *handle = nullptr;
@@ -92,14 +93,84 @@ bool star_shaped(const brk_expr_op *ops, uint32_t nops) {
 // waves per workgroup of the generated kernel = CubeWaves<R> / StarWaves<R> of brick-device.h
 uint32_t waves_per_group(int R, bool star) { return star ? (R <= 2 ? 4u : 2u) : (R <= 2 ? 4u : (R == 3 ? 2u : 1u)); }
 
+// The kernels a star-shaped program of radius 1 instantiates: k_s7_wg<kUser, 8, kModeList / kModeRange> of brk_star7_kernel.h in namespace
+// brklib::jit (Itanium names of the explicit instantiations the generated unit ends with)
+const char kS7List[] = "_ZN6brklib3jit7k_s7_wgILi3ELi8ELi1ELi0ELi0EEEvPKjPKdPdmS3_jjNS0_3BoxENS_6CoeffsES3_S3_";
+const char kS7Range[] = "_ZN6brklib3jit7k_s7_wgILi3ELi8ELi0ELi0ELi0EEEvPKjPKdPdmS3_jjNS0_3BoxENS_6CoeffsES3_S3_";
+
+void statement_rhs(const brk_expr_op &o, const char *tap, char (&rhs)[160]) {
+  char a[16], b[16], c[16];
+  snprintf(a, sizeof a, "r%u", o.a), snprintf(b, sizeof b, "r%u", o.b), snprintf(c, sizeof c, "r%u", o.c);
+  switch (o.code) {
+  case BRK_EX_TAP: snprintf(rhs, sizeof rhs, "%s", tap); break;
+  case BRK_EX_CONST: snprintf(rhs, sizeof rhs, "%a", o.imm); break; // hexadecimal floating literal: the exact value
+  case BRK_EX_ADD: snprintf(rhs, sizeof rhs, "%s + %s", a, b); break;
+  case BRK_EX_SUB: snprintf(rhs, sizeof rhs, "%s - %s", a, b); break;
+  case BRK_EX_MUL: snprintf(rhs, sizeof rhs, "%s * %s", a, b); break;
+  case BRK_EX_DIV: snprintf(rhs, sizeof rhs, "%s / %s", a, b); break;
+  case BRK_EX_NEG: snprintf(rhs, sizeof rhs, "-%s", a); break;
+  case BRK_EX_MAX: snprintf(rhs, sizeof rhs, "%s > %s ? %s : %s", a, b, a, b); break;
+  case BRK_EX_MIN: snprintf(rhs, sizeof rhs, "%s < %s ? %s : %s", a, b, a, b); break;
+  case BRK_EX_ABS: snprintf(rhs, sizeof rhs, "%s < 0 ? -%s : %s", a, a, a); break;
+  case BRK_EX_SQRT: snprintf(rhs, sizeof rhs, "__builtin_sqrt(%s)", a); break;
+  case BRK_EX_GT: snprintf(rhs, sizeof rhs, "%s > %s ? 1.0 : 0.0", a, b); break;
+  case BRK_EX_GE: snprintf(rhs, sizeof rhs, "%s >= %s ? 1.0 : 0.0", a, b); break;
+  case BRK_EX_LT: snprintf(rhs, sizeof rhs, "%s < %s ? 1.0 : 0.0", a, b); break;
+  case BRK_EX_LE: snprintf(rhs, sizeof rhs, "%s <= %s ? 1.0 : 0.0", a, b); break;
+  case BRK_EX_EQ: snprintf(rhs, sizeof rhs, "%s == %s ? 1.0 : 0.0", a, b); break;
+  case BRK_EX_NE: snprintf(rhs, sizeof rhs, "%s != %s ? 1.0 : 0.0", a, b); break;
+  default: snprintf(rhs, sizeof rhs, "%s != 0.0 ? %s : %s", a, b, c); break; // BRK_EX_SEL
+  }
+  if (o.code == BRK_EX_CONST && (o.imm != o.imm || o.imm - o.imm != 0.0)) // NaN / infinity have no literal
+    snprintf(rhs, sizeof rhs, "%s", o.imm != o.imm ? "__builtin_nan(\"\")" : (o.imm > 0 ? "__builtin_inf()" : "-__builtin_inf()"));
+}
+
+std::string declare_registers(const brk_expr_op *ops, uint32_t nops) {
+  std::string s = "    double";
+  bool used[BRK_EXPR_MAX_REGS] = {};
+  for (uint32_t t = 0; t < nops; ++t) used[ops[t].dst] = true;
+  bool first = true;
+  char buf[16];
+  for (int r = 0; r < BRK_EXPR_MAX_REGS; ++r)
+    if (used[r]) snprintf(buf, sizeof buf, "%s r%d", first ? "" : ",", r), s += buf, first = false;
+  return s + ";\n";
+}
+
+const char kTypedefs[] = // hiprtc brings the runtime's declarations but no <cstdint>
+    "typedef unsigned char uint8_t; typedef signed char int8_t; typedef unsigned short uint16_t; typedef short int16_t; typedef int int32_t;\n"
+    "typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t; typedef unsigned long uintptr_t;\n";
+
+// A star-shaped program of radius 1 (the shape of the 7-point stencils and of stencils/cond.py): the HEADLINE kernel k_s7_wg -- eight
+// bricks per workgroup, i-faces out of the sibling waves' tiles, k in registers -- instantiated around the program as its cell update.
+std::string generate_s7(const brk_expr_op *ops, uint32_t nops, uint32_t result) {
+  std::string s = "// generated by brk_expr_compile (bricklib_amd/csrc/brk_jit.hip): the program as the cell update of k_s7_wg\n";
+  s += kTypedefs;
+  s += "#define BRK_JIT_POINT7\n#include \"brk_star7_kernel.h\"\nnamespace brklib {\nnamespace jit {\n"
+       "__device__ __forceinline__ double brk_user_point7(double kp, double km, double jp, double jm, double ip, double im, double c0) {\n";
+  s += declare_registers(ops, nops);
+  char buf[256], rhs[160];
+  for (uint32_t t = 0; t < nops; ++t) {
+    const brk_expr_op &o = ops[t];
+    const char *tap = o.offset[0] ? (o.offset[0] > 0 ? "ip" : "im") : (o.offset[1] ? (o.offset[1] > 0 ? "jp" : "jm") : (o.offset[2] ? (o.offset[2] > 0 ? "kp" : "km") : "c0"));
+    statement_rhs(o, tap, rhs);
+    snprintf(buf, sizeof buf, "    r%u = %s;\n", o.dst, rhs);
+    s += buf;
+  }
+  snprintf(buf, sizeof buf, "    return r%u;\n}\n", result);
+  s += buf;
+  s += "template __global__ void k_s7_wg<kUser, 8, kModeList>(const uint32_t *, const double *, double *, size_t, const uint32_t *, uint32_t, uint32_t, Box, Coeffs, const uint32_t *, const uint32_t *);\n"
+       "template __global__ void k_s7_wg<kUser, 8, kModeRange>(const uint32_t *, const double *, double *, size_t, const uint32_t *, uint32_t, uint32_t, Box, Coeffs, const uint32_t *, const uint32_t *);\n"
+       "} // namespace jit\n} // namespace brklib\n";
+  return s;
+}
+
 std::string generate(const brk_expr_op *ops, uint32_t nops, uint32_t result, int R) {
   std::string s;
   const bool star = star_shaped(ops, nops);
+  if (star && R == 1) return generate_s7(ops, nops, result);
   s += "// generated by brk_expr_compile (bricklib_amd/csrc/brk_jit.hip)\n";
-  // hiprtc brings the runtime's declarations but no <cstdint>
-  s += "typedef unsigned char uint8_t; typedef signed char int8_t; typedef unsigned short uint16_t; typedef short int16_t; typedef int int32_t;\n"
-       "typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t; typedef unsigned long uintptr_t;\n"
-       "#include \"brick-device.h\"\n"
+  s += kTypedefs;
+  s += "#include \"brick-device.h\"\n"
        "#define BRK_JIT_R " + std::to_string(R) + "\n"
        "#define BRK_JIT_WAVES brklib::" + (star ? "StarWaves" : "CubeWaves") + "<BRK_JIT_R>::WAVES\n"
        "extern \"C\" __global__ __launch_bounds__(64 * BRK_JIT_WAVES) void k_expr_jit(const uint32_t *__restrict__ adj, const double *__restrict__ in, double *__restrict__ out,\n"
@@ -110,49 +181,19 @@ std::string generate(const brk_expr_op *ops, uint32_t nops, uint32_t result, int
        "  if (slot >= n) return;\n"
        "  const uint32_t b = __builtin_amdgcn_readfirstlane(ids ? ids[slot] : first + slot);\n"
        "  if (b == BRK_LIST_SKIP) return;\n";
-  char buf[256];
+  char buf[256], rhs[160], tap[64];
   // star-shaped programs (every tap on one axis): the star staging, no edge / corner gathers
-  if (star) snprintf(buf, sizeof buf, "  brklib::brick_apply_star_fn<%d>(adj, in, out, step, b, [](const double *ti, const double *tj, const double *ck) -> double {\n    double", R);
-  else snprintf(buf, sizeof buf, "  brklib::brick_apply_fn<%d>(adj, in, out, step, b, [](const double *c) -> double {\n    double", R);
+  if (star) snprintf(buf, sizeof buf, "  brklib::brick_apply_star_fn<%d>(adj, in, out, step, b, [](const double *ti, const double *tj, const double *ck) -> double {\n", R);
+  else snprintf(buf, sizeof buf, "  brklib::brick_apply_fn<%d>(adj, in, out, step, b, [](const double *c) -> double {\n", R);
   s += buf;
-  bool used[BRK_EXPR_MAX_REGS] = {};
-  for (uint32_t t = 0; t < nops; ++t) used[ops[t].dst] = true;
-  bool first = true;
-  for (int r = 0; r < BRK_EXPR_MAX_REGS; ++r)
-    if (used[r]) snprintf(buf, sizeof buf, "%s r%d", first ? "" : ",", r), s += buf, first = false;
-  s += ";\n";
+  s += declare_registers(ops, nops);
   for (uint32_t t = 0; t < nops; ++t) {
     const brk_expr_op &o = ops[t];
-    char a[8], b[8], c[8];
-    snprintf(a, sizeof a, "r%u", o.a), snprintf(b, sizeof b, "r%u", o.b), snprintf(c, sizeof c, "r%u", o.c);
-    char rhs[160];
-    switch (o.code) {
-    case BRK_EX_TAP:
-      if (!star) snprintf(rhs, sizeof rhs, "c[brklib::tap_rel<%d>(%d, %d, %d)]", R, o.offset[0], o.offset[1], o.offset[2]);
-      else if (o.offset[0]) snprintf(rhs, sizeof rhs, "ti[%d]", o.offset[0]);
-      else if (o.offset[1]) snprintf(rhs, sizeof rhs, "tj[%d]", 8 * o.offset[1]);
-      else snprintf(rhs, sizeof rhs, "ck[%d]", o.offset[2]);
-      break;
-    case BRK_EX_CONST: snprintf(rhs, sizeof rhs, "%a", o.imm); break; // hexadecimal floating literal: the exact value
-    case BRK_EX_ADD: snprintf(rhs, sizeof rhs, "%s + %s", a, b); break;
-    case BRK_EX_SUB: snprintf(rhs, sizeof rhs, "%s - %s", a, b); break;
-    case BRK_EX_MUL: snprintf(rhs, sizeof rhs, "%s * %s", a, b); break;
-    case BRK_EX_DIV: snprintf(rhs, sizeof rhs, "%s / %s", a, b); break;
-    case BRK_EX_NEG: snprintf(rhs, sizeof rhs, "-%s", a); break;
-    case BRK_EX_MAX: snprintf(rhs, sizeof rhs, "%s > %s ? %s : %s", a, b, a, b); break;
-    case BRK_EX_MIN: snprintf(rhs, sizeof rhs, "%s < %s ? %s : %s", a, b, a, b); break;
-    case BRK_EX_ABS: snprintf(rhs, sizeof rhs, "%s < 0 ? -%s : %s", a, a, a); break;
-    case BRK_EX_SQRT: snprintf(rhs, sizeof rhs, "__builtin_sqrt(%s)", a); break;
-    case BRK_EX_GT: snprintf(rhs, sizeof rhs, "%s > %s ? 1.0 : 0.0", a, b); break;
-    case BRK_EX_GE: snprintf(rhs, sizeof rhs, "%s >= %s ? 1.0 : 0.0", a, b); break;
-    case BRK_EX_LT: snprintf(rhs, sizeof rhs, "%s < %s ? 1.0 : 0.0", a, b); break;
-    case BRK_EX_LE: snprintf(rhs, sizeof rhs, "%s <= %s ? 1.0 : 0.0", a, b); break;
-    case BRK_EX_EQ: snprintf(rhs, sizeof rhs, "%s == %s ? 1.0 : 0.0", a, b); break;
-    case BRK_EX_NE: snprintf(rhs, sizeof rhs, "%s != %s ? 1.0 : 0.0", a, b); break;
-    default: snprintf(rhs, sizeof rhs, "%s != 0.0 ? %s : %s", a, b, c); break; // BRK_EX_SEL
-    }
-    if (o.code == BRK_EX_CONST && (o.imm != o.imm || o.imm - o.imm != 0.0)) // NaN / infinity have no literal
-      snprintf(rhs, sizeof rhs, "%s", o.imm != o.imm ? "__builtin_nan(\"\")" : (o.imm > 0 ? "__builtin_inf()" : "-__builtin_inf()"));
+    if (!star) snprintf(tap, sizeof tap, "c[brklib::tap_rel<%d>(%d, %d, %d)]", R, o.offset[0], o.offset[1], o.offset[2]);
+    else if (o.offset[0]) snprintf(tap, sizeof tap, "ti[%d]", o.offset[0]);
+    else if (o.offset[1]) snprintf(tap, sizeof tap, "tj[%d]", 8 * o.offset[1]);
+    else snprintf(tap, sizeof tap, "ck[%d]", o.offset[2]);
+    statement_rhs(o, tap, rhs);
     snprintf(buf, sizeof buf, "    r%u = %s;\n", o.dst, rhs);
     s += buf;
   }
@@ -170,9 +211,10 @@ uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
 
 struct brk_expr_kernel {
   hipModule_t module = nullptr;
-  hipFunction_t fn = nullptr;
+  hipFunction_t fn = nullptr, fn_range = nullptr; // s7 form: the list and the range instantiation of k_s7_wg; else one kernel
   int radius = 1, device = 0;
   bool star = false, from_disk = false;
+  bool s7() const { return star && radius == 1; }
   std::string source, code; // generated text; the code object (kept: brk_finalize unloads the module, a later compile of the same program loads it again)
 };
 
@@ -255,10 +297,11 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   auto load = [](brk_expr_kernel *k) -> int {
     hipError_t e = hipModuleLoadData(&k->module, k->code.data());
     if (e != hipSuccess) return brk_fail(BRK_EHIP, "hipModuleLoadData: %s", hipGetErrorString(e));
-    e = hipModuleGetFunction(&k->fn, k->module, "k_expr_jit");
+    e = hipModuleGetFunction(&k->fn, k->module, k->s7() ? kS7List : "k_expr_jit");
+    if (e == hipSuccess && k->s7()) e = hipModuleGetFunction(&k->fn_range, k->module, kS7Range);
     if (e != hipSuccess) {
       (void)hipModuleUnload(k->module);
-      k->module = nullptr, k->fn = nullptr;
+      k->module = nullptr, k->fn = nullptr, k->fn_range = nullptr;
       return brk_fail(BRK_EHIP, "hipModuleGetFunction: %s", hipGetErrorString(e));
     }
     return BRK_OK;
@@ -275,7 +318,7 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   // covers everything the code depends on: generated text, the two embedded headers, target, options
   std::string disk;
   if (const char *dir = getenv("BRK_JIT_CACHE_DIR"); dir && *dir && have_device) {
-    static const uint64_t hdr_hash = fnv(kJitAbiHeader, sizeof kJitAbiHeader, fnv(kJitDeviceHeader, sizeof kJitDeviceHeader));
+    static const uint64_t hdr_hash = fnv(kJitStar7Header, sizeof kJitStar7Header, fnv(kJitSbaseHeader, sizeof kJitSbaseHeader, fnv(kJitAbiHeader, sizeof kJitAbiHeader, fnv(kJitDeviceHeader, sizeof kJitDeviceHeader))));
     const uint64_t h1 = fnv(arch, std::strlen(arch), fnv(src.data(), src.size(), hdr_hash)), h2 = fnv(src.data(), src.size(), 0x9e3779b97f4a7c15ull ^ hdr_hash);
     char name[96];
     snprintf(name, sizeof name, "/brk_expr_%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
@@ -301,9 +344,9 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   Rtc *rt = rtc();
   if (!rt) return brk_fail(BRK_ENODEV, "%s (brk_stencil_apply_expr runs a program without a compiler)", rtc_state().why);
   hiprtcProgram prog = nullptr;
-  const char *hdr[] = {kJitDeviceHeader, kJitAbiHeader};
-  const char *names[] = {"brick-device.h", "brk.h"};
-  hiprtcResult r = rt->Create(&prog, src.c_str(), "k_expr_jit.hip", 2, hdr, names);
+  const char *hdr[] = {kJitDeviceHeader, kJitAbiHeader, kJitSbaseHeader, kJitStar7Header};
+  const char *names[] = {"brick-device.h", "brk.h", "brk_sbase.h", "brk_star7_kernel.h"};
+  hiprtcResult r = rt->Create(&prog, src.c_str(), "k_expr_jit.hip", 4, hdr, names);
   if (r != HIPRTC_SUCCESS) return brk_fail(BRK_EHIP, "hiprtcCreateProgram: %s", rt->ErrorString(r));
   // -ffp-contract=off: a script's `a * b + c` stays two roundings, as in the interpreter and in the checker
   const char *opts[] = {arch, "-O3", "-std=c++17", "-ffp-contract=off"};
@@ -348,13 +391,25 @@ extern "C" int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj, con
   if (!adj || !in || !out || in == out) return brk_fail(BRK_EINVAL, "bad device pointers");
   if (step < 512) return brk_fail(BRK_EINVAL, "step_elems %zu < 512", step);
   if (n == 0) return BRK_OK;
-  const uint32_t wpw = waves_per_group(k->radius, k->star);
-  const uint32_t wgs = (((n + wpw - 1) / wpw + 7) / 8) * 8;
-  void *args[] = {&adj, &in, &out, &step, &ids, &first, &n};
-  static const char *const names[] = {"k_expr_jit<1>", "k_expr_jit<2>", "k_expr_jit<3>", "k_expr_jit<4>",
-                                      "k_expr_jit<1,star>", "k_expr_jit<2,star>", "k_expr_jit<3,star>", "k_expr_jit<4,star>"};
-  brki_note_kernel(names[k->radius - 1 + (k->star ? 4 : 0)]);
-  hipError_t e = hipModuleLaunchKernel(k->fn, wgs, 1, 1, 64 * wpw, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
+  hipError_t e;
+  if (k->s7()) { // k_s7_wg<kUser, 8, list / range>: eight bricks per workgroup, (adj, in, out, step, ids, first, n, Box, Coeffs, regmask, faces)
+    struct { uint32_t base, ni_tot, nj_tot, lo[3], cnt[3]; } box = {}; // = brklib::Box of brk_star7_kernel.h (box mode only)
+    brklib::Coeffs cf;
+    std::memset(&cf, 0, sizeof cf);
+    const uint32_t *none = nullptr;
+    const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
+    void *args[] = {&adj, &in, &out, &step, &ids, &first, &n, &box, &cf, &none, &none};
+    brki_note_kernel(ids ? "k_expr_jit<1,s7,list>" : "k_expr_jit<1,s7,range>");
+    e = hipModuleLaunchKernel(ids ? k->fn : k->fn_range, wgs, 1, 1, 512, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
+  } else {
+    const uint32_t wpw = waves_per_group(k->radius, k->star);
+    const uint32_t wgs = (((n + wpw - 1) / wpw + 7) / 8) * 8;
+    void *args[] = {&adj, &in, &out, &step, &ids, &first, &n};
+    static const char *const names[] = {"k_expr_jit<1>", "k_expr_jit<2>", "k_expr_jit<3>", "k_expr_jit<4>",
+                                        "k_expr_jit<1,star>", "k_expr_jit<2,star>", "k_expr_jit<3,star>", "k_expr_jit<4,star>"};
+    brki_note_kernel(names[k->radius - 1 + (k->star ? 4 : 0)]);
+    e = hipModuleLaunchKernel(k->fn, wgs, 1, 1, 64 * wpw, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
+  }
   if (e != hipSuccess) return brk_fail(BRK_EHIP, "hipModuleLaunchKernel: %s", hipGetErrorString(e));
   return BRK_OK;
 }
@@ -381,6 +436,6 @@ extern "C" void brki_jit_finalize(void) {
   for (auto &kv : cache())
     if (kv.second.k && kv.second.k->module) {
       (void)hipModuleUnload(kv.second.k->module);
-      kv.second.k->module = nullptr, kv.second.k->fn = nullptr; // handles stay valid objects; brk_expr_apply refuses them until the program is compiled again
+      kv.second.k->module = nullptr, kv.second.k->fn = nullptr, kv.second.k->fn_range = nullptr; // handles stay valid objects; brk_expr_apply refuses them until the program is compiled again
     }
 }

@@ -1019,9 +1019,11 @@ def test_stencil_given_as_expression(oracle, dev, case):
     ck = bl.CompiledExpr(spec, consts)
     sc = bl.BrickStorage.allocate(info.nbricks, 512, dev)
     ck.apply(bl.Brick(info, st, 0), bl.Brick(info, sc, 0), ids=grid_to_device(lst, dev))
-    star = all(sum(1 for x in o["offset"] if x) <= 1 for o in spec.program(consts)[0])       # every tap on one axis: star staging
-    assert bl.last_kernel() == "k_expr_jit<%d%s>" % (spec.radius, ",star" if star else "") and star == (case in ("cond", "norm"))
-    assert torch.equal(sc.dat, so.dat) and ("brick_apply_star_fn" if star else "brick_apply_fn<") in ck.source
+    star = all(sum(1 for x in o["offset"] if x) <= 1 for o in spec.program(consts)[0])       # every tap on one axis
+    # star-shaped of radius 1: the 7-point kernel k_s7_wg around the program; other stars: the star staging; else the cube tile
+    form = ",s7,list" if star and spec.radius == 1 else (",star" if star else "")
+    assert bl.last_kernel() == "k_expr_jit<%d%s>" % (spec.radius, form) and star == (case in ("cond", "norm"))
+    assert torch.equal(sc.dat, so.dat) and ("brk_user_point7" if form.startswith(",s7") else "brick_apply_star_fn" if star else "brick_apply_fn<") in ck.source
     if case == "cond":
         sb = bl.BrickStorage.allocate(info.nbricks, 512, dev)
         bl.apply_stencil("cond", bl.Brick(info, st, 0), bl.Brick(info, sb, 0), ids=grid_to_device(lst, dev), coeff=coeff)
@@ -1039,7 +1041,7 @@ def test_stencil_given_as_expression(oracle, dev, case):
     agree(B.dat.cpu().numpy(), want2)
     C = dinfo.allocate(512, dev)
     ck.apply(bl.Brick(dinfo, A, 0), bl.Brick(dinfo, C, 0), brick_range=(1, d.sep_pos[2]))
-    assert torch.equal(C.dat, B.dat)
+    assert torch.equal(C.dat, B.dat) and bl.last_kernel() == "k_expr_jit<%d%s>" % (spec.radius, form.replace("list", "range"))
     ck.release()
 
 

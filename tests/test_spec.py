@@ -219,10 +219,15 @@ def test_expression_source_generation_and_compilation_without_a_device():
     cube = expr_source(load_spec(PRELUDE + NONLINEAR[1].replace("g(i + 1, j, k)", "g(i + 1, j - 2, k)")))
     assert "brklib::brick_apply_fn<2>(" in cube and "c[brklib::tap_rel<2>(1, -2, 0)]" in cube
     assert expr_source(s, {"lim": 0.75}) == text and expr_source(s, {"lim": 0.5}) != text
+    # a star-shaped program of radius 1: the 7-point kernel itself, instantiated around the program as its cell update
+    seven = expr_source(load_spec(COND_LIKE), {"coeff": [0.1] * 7})
+    assert "brk_user_point7(double kp, double km, double jp, double jm, double ip, double im, double c0)" in seven
+    assert "template __global__ void k_s7_wg<kUser, 8, kModeList>(" in seven and "r0 = kp;" in seven
     if torch.cuda.is_available():
         return
-    with pytest.raises(BrkError, match="compiled for gfx950 .* no device|libhiprtc"):
-        CompiledExpr(s, {"lim": 0.75})
+    for sp, consts in ((s, {"lim": 0.75}), (load_spec(COND_LIKE), {"coeff": [0.1] * 7})):
+        with pytest.raises(BrkError, match="compiled for gfx950 .* no device|libhiprtc"):
+            CompiledExpr(sp, consts)
 
 
 @pytest.mark.parametrize("steps", [14, 45])
