@@ -20,6 +20,14 @@ int brki_expr_check(const brk_expr_op *ops, uint32_t nops, uint32_t max_ops, uin
 #ifdef __cplusplus
 extern "C"
 #endif
+int brki_face_table_lock(const uint32_t *adj_dev, const uint32_t **faces); // brk_kernels.hip: compact face rows of a REGISTERED adjacency table, else
+#ifdef __cplusplus
+extern "C"
+#endif
+void brki_adj_unlock(void); // nullptr; BRK_OK leaves the tables' mutex taken until brki_adj_unlock (after the launch is enqueued)
+#ifdef __cplusplus
+extern "C"
+#endif
 void brki_jit_finalize(void); // brk_finalize: unload the modules of brk_expr_compile
 enum { BRK_EXPR_MAX_OPS = 120, BRK_EXPR_MAX_REGS = 16, BRK_EXPR_COMPILE_MAX_OPS = 512 }; // interpreter: the program is a kernel argument; compiled: text (straight-line code: a
 // 125-tap linear sum of 501 operations already runs slower than the tap table, 3.4 vs 2.05 ms per 512^3 sweep, and 1 371 operations spill)

@@ -396,11 +396,13 @@ extern "C" int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj, con
     struct { uint32_t base, ni_tot, nj_tot, lo[3], cnt[3]; } box = {}; // = brklib::Box of brk_star7_kernel.h (box mode only)
     brklib::Coeffs cf;
     std::memset(&cf, 0, sizeof cf);
-    const uint32_t *none = nullptr;
+    const uint32_t *none = nullptr, *faces = nullptr; // a registered adjacency table: one 32-byte row of face ids per brick instead of the 108-byte row
+    if (int rc = brki_face_table_lock(adj, &faces)) return rc;
     const uint32_t wgs = (((n + 7) / 8 + 7) / 8) * 8;
-    void *args[] = {&adj, &in, &out, &step, &ids, &first, &n, &box, &cf, &none, &none};
+    void *args[] = {&adj, &in, &out, &step, &ids, &first, &n, &box, &cf, &none, &faces};
     brki_note_kernel(ids ? "k_expr_jit<1,s7,list>" : "k_expr_jit<1,s7,range>");
     e = hipModuleLaunchKernel(ids ? k->fn : k->fn_range, wgs, 1, 1, 512, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
+    brki_adj_unlock();
   } else {
     const uint32_t wpw = waves_per_group(k->radius, k->star);
     const uint32_t wgs = (((n + wpw - 1) / wpw + 7) / 8) * 8;

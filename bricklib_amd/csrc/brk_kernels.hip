@@ -678,6 +678,16 @@ int face_table_locked(const uint32_t *adj, const uint32_t **out) {
   return e ? same_device(*e) : BRK_OK;
 }
 
+// for brk_expr_apply (brk_jit.hip): the compact face rows of a registered table, or nullptr.  Lifetime rule as for every launch path:
+// g_adj_mutex is taken here and stays taken until the caller has enqueued its launch (brki_adj_unlock)
+extern "C" int brki_face_table_lock(const uint32_t *adj, const uint32_t **out) {
+  g_adj_mutex.lock();
+  const int rc = face_table_locked(adj, out);
+  if (rc != BRK_OK) g_adj_mutex.unlock();
+  return rc;
+}
+extern "C" void brki_adj_unlock(void) { g_adj_mutex.unlock(); }
+
 int link_mask_locked(const uint32_t *adj, const uint32_t **out) {
   const AdjEntry *e = find_locked(adj);
   *out = e ? e->linkmask : nullptr;
