@@ -27,7 +27,7 @@
 #include "brk_internal.h"
 
 namespace {
-#include "brk_jit_headers.inc" // kJitDeviceHeader (brick-device.h), kJitAbiHeader (brk.h), kJitSbaseHeader (brk_sbase.h), kJitStar7Header (brk_star7_kernel.h)
+#include "brk_jit_headers.inc" // kJitDeviceHeader (brick-device.h), kJitAbiHeader (brk.h), kJitSbaseHeader (brk_sbase.h), kJitStar7Header (brk_star7_kernel.h), kJitStarWgHeader (brk_starwg_kernel.h)
 
 struct Rtc {
   void *handle = nullptr;
@@ -98,6 +98,11 @@ uint32_t waves_per_group(int R, bool star) { return star ? (R <= 2 ? 4u : 2u) : 
 const char kS7List[] = "_ZN6brklib3jit7k_s7_wgILi3ELi8ELi1ELi0ELi0EEEvPKjPKdPdmS3_jjNS0_3BoxENS_6CoeffsES3_S3_";
 const char kS7Range[] = "_ZN6brklib3jit7k_s7_wgILi3ELi8ELi0ELi0ELi0EEEvPKjPKdPdmS3_jjNS0_3BoxENS_6CoeffsES3_S3_";
 
+// ... and a star-shaped program of radius 2, 3 or 4: k_star_wg<kStarUser2, 4, 4> / <kStarUser4, 4, 3> of brk_starwg_kernel.h
+// (radius 2 at four groups per CU; five, like the built-in 13-point kernel, measured the same for a 13-tap program: 0.477 vs 0.475 ms)
+const char kSw2[] = "_ZN6brklib3jit9k_star_wgILi5ELi4ELi4ELi0EEEvPKjPKdPdmS3_jjNS_6CoeffsES3_";
+const char kSw4[] = "_ZN6brklib3jit9k_star_wgILi6ELi4ELi3ELi0EEEvPKjPKdPdmS3_jjNS_6CoeffsES3_";
+
 void statement_rhs(const brk_expr_op &o, const char *tap, char (&rhs)[160]) {
   char a[16], b[16], c[16];
   snprintf(a, sizeof a, "r%u", o.a), snprintf(b, sizeof b, "r%u", o.b), snprintf(c, sizeof c, "r%u", o.c);
@@ -164,10 +169,38 @@ std::string generate_s7(const brk_expr_op *ops, uint32_t nops, uint32_t result) 
   return s;
 }
 
+// A star-shaped program of radius 2..4 (finite-difference scripts of higher order): the radius-2 / radius-4 star kernel k_star_wg -- four
+// bricks per workgroup, i-columns out of the sibling waves' tiles, the k-column in registers -- around the program as its cell update.
+std::string generate_sw(const brk_expr_op *ops, uint32_t nops, uint32_t result, int R) {
+  std::string s = "// generated by brk_expr_compile (bricklib_amd/csrc/brk_jit.hip): the program as the cell update of k_star_wg\n";
+  s += kTypedefs;
+  s += "#define BRK_JIT_STAR\n#include \"brk_starwg_kernel.h\"\nnamespace brklib {\nnamespace jit {\n"
+       "__device__ __forceinline__ double brk_user_star(const double *ck, const double *jm, const double *jp, const double *im, const double *ip) {\n";
+  s += declare_registers(ops, nops);
+  char buf[256], rhs[160], tap[32];
+  for (uint32_t t = 0; t < nops; ++t) {
+    const brk_expr_op &o = ops[t];
+    const int di = o.offset[0], dj = o.offset[1], dk = o.offset[2];
+    if (di) snprintf(tap, sizeof tap, "%s[%d]", di > 0 ? "ip" : "im", (di > 0 ? di : -di) - 1);
+    else if (dj) snprintf(tap, sizeof tap, "%s[%d]", dj > 0 ? "jp" : "jm", (dj > 0 ? dj : -dj) - 1);
+    else snprintf(tap, sizeof tap, "ck[%d]", dk);
+    statement_rhs(o, tap, rhs);
+    snprintf(buf, sizeof buf, "    r%u = %s;\n", o.dst, rhs);
+    s += buf;
+  }
+  snprintf(buf, sizeof buf, "    return r%u;\n}\n", result);
+  s += buf;
+  s += R == 2 ? "template __global__ void k_star_wg<kStarUser2, 4, 4>(" : "template __global__ void k_star_wg<kStarUser4, 4, 3>(";
+  s += "const uint32_t *, const double *, double *, size_t, const uint32_t *, uint32_t, uint32_t, Coeffs, const uint32_t *);\n"
+       "} // namespace jit\n} // namespace brklib\n";
+  return s;
+}
+
 std::string generate(const brk_expr_op *ops, uint32_t nops, uint32_t result, int R) {
   std::string s;
   const bool star = star_shaped(ops, nops);
   if (star && R == 1) return generate_s7(ops, nops, result);
+  if (star) return generate_sw(ops, nops, result, R == 2 ? 2 : 4); // radius 3 runs on the radius-4 kernel
   s += "// generated by brk_expr_compile (bricklib_amd/csrc/brk_jit.hip)\n";
   s += kTypedefs;
   s += "#include \"brick-device.h\"\n"
@@ -297,7 +330,7 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   auto load = [](brk_expr_kernel *k) -> int {
     hipError_t e = hipModuleLoadData(&k->module, k->code.data());
     if (e != hipSuccess) return brk_fail(BRK_EHIP, "hipModuleLoadData: %s", hipGetErrorString(e));
-    e = hipModuleGetFunction(&k->fn, k->module, k->s7() ? kS7List : "k_expr_jit");
+    e = hipModuleGetFunction(&k->fn, k->module, k->s7() ? kS7List : (k->star ? (k->radius == 2 ? kSw2 : kSw4) : "k_expr_jit"));
     if (e == hipSuccess && k->s7()) e = hipModuleGetFunction(&k->fn_range, k->module, kS7Range);
     if (e != hipSuccess) {
       (void)hipModuleUnload(k->module);
@@ -318,7 +351,7 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   // covers everything the code depends on: generated text, the two embedded headers, target, options
   std::string disk;
   if (const char *dir = getenv("BRK_JIT_CACHE_DIR"); dir && *dir && have_device) {
-    static const uint64_t hdr_hash = fnv(kJitStar7Header, sizeof kJitStar7Header, fnv(kJitSbaseHeader, sizeof kJitSbaseHeader, fnv(kJitAbiHeader, sizeof kJitAbiHeader, fnv(kJitDeviceHeader, sizeof kJitDeviceHeader))));
+    static const uint64_t hdr_hash = fnv(kJitStarWgHeader, sizeof kJitStarWgHeader, fnv(kJitStar7Header, sizeof kJitStar7Header, fnv(kJitSbaseHeader, sizeof kJitSbaseHeader, fnv(kJitAbiHeader, sizeof kJitAbiHeader, fnv(kJitDeviceHeader, sizeof kJitDeviceHeader)))));
     const uint64_t h1 = fnv(arch, std::strlen(arch), fnv(src.data(), src.size(), hdr_hash)), h2 = fnv(src.data(), src.size(), 0x9e3779b97f4a7c15ull ^ hdr_hash);
     char name[96];
     snprintf(name, sizeof name, "/brk_expr_%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
@@ -344,9 +377,9 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   Rtc *rt = rtc();
   if (!rt) return brk_fail(BRK_ENODEV, "%s (brk_stencil_apply_expr runs a program without a compiler)", rtc_state().why);
   hiprtcProgram prog = nullptr;
-  const char *hdr[] = {kJitDeviceHeader, kJitAbiHeader, kJitSbaseHeader, kJitStar7Header};
-  const char *names[] = {"brick-device.h", "brk.h", "brk_sbase.h", "brk_star7_kernel.h"};
-  hiprtcResult r = rt->Create(&prog, src.c_str(), "k_expr_jit.hip", 4, hdr, names);
+  const char *hdr[] = {kJitDeviceHeader, kJitAbiHeader, kJitSbaseHeader, kJitStar7Header, kJitStarWgHeader};
+  const char *names[] = {"brick-device.h", "brk.h", "brk_sbase.h", "brk_star7_kernel.h", "brk_starwg_kernel.h"};
+  hiprtcResult r = rt->Create(&prog, src.c_str(), "k_expr_jit.hip", 5, hdr, names);
   if (r != HIPRTC_SUCCESS) return brk_fail(BRK_EHIP, "hiprtcCreateProgram: %s", rt->ErrorString(r));
   // -ffp-contract=off: a script's `a * b + c` stays two roundings, as in the interpreter and in the checker
   const char *opts[] = {arch, "-O3", "-std=c++17", "-ffp-contract=off"};
@@ -402,6 +435,16 @@ extern "C" int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj, con
     void *args[] = {&adj, &in, &out, &step, &ids, &first, &n, &box, &cf, &none, &faces};
     brki_note_kernel(ids ? "k_expr_jit<1,s7,list>" : "k_expr_jit<1,s7,range>");
     e = hipModuleLaunchKernel(ids ? k->fn : k->fn_range, wgs, 1, 1, 512, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
+    brki_adj_unlock();
+  } else if (k->star) { // k_star_wg<kStarUser2 | kStarUser4, 4, OCC>: four bricks per workgroup, (adj, in, out, step, ids, first, n, Coeffs, faces)
+    brklib::Coeffs cf;
+    std::memset(&cf, 0, sizeof cf);
+    const uint32_t *faces = nullptr;
+    if (int rc = brki_face_table_lock(adj, &faces)) return rc;
+    const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
+    void *args[] = {&adj, &in, &out, &step, &ids, &first, &n, &cf, &faces};
+    brki_note_kernel(k->radius == 2 ? "k_expr_jit<2,star_wg>" : (k->radius == 3 ? "k_expr_jit<3,star_wg>" : "k_expr_jit<4,star_wg>"));
+    e = hipModuleLaunchKernel(k->fn, wgs, 1, 1, 256, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
     brki_adj_unlock();
   } else {
     const uint32_t wpw = waves_per_group(k->radius, k->star);

@@ -73,7 +73,7 @@ struct StarTile {
   __device__ static constexpr int ti(int k, int j, int ii) { return TJ_ELEMS + (k * 8 + j) * PI + ii; }
 };
 
-enum StarKind { kStar7Coeff, kStarMpi7, kStarMpi13, kStarMpi25, kStarCond7 };
+enum StarKind { kStar7Coeff, kStarMpi7, kStarMpi13, kStarMpi25, kStarCond7, kStarUser2, kStarUser4 }; // kStarUser*: run-time compiled cell updates (brk_expr_compile)
 
 template <int KIND>
 struct StarTraits;
@@ -82,6 +82,8 @@ template <> struct StarTraits<kStarMpi7> { static constexpr int R = 1; };
 template <> struct StarTraits<kStarMpi13> { static constexpr int R = 2; };
 template <> struct StarTraits<kStarMpi25> { static constexpr int R = 4; };
 template <> struct StarTraits<kStarCond7> { static constexpr int R = 1; };
+template <> struct StarTraits<kStarUser2> { static constexpr int R = 2; };
+template <> struct StarTraits<kStarUser4> { static constexpr int R = 4; };
 
 // One wave computes brick `b` (wave-uniform).  `tile` = this wave's private LDS slice of StarTile<R>::ELEMS doubles.
 template <int KIND>

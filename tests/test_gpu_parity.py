@@ -972,6 +972,23 @@ u = Grid("u", 3); v = Grid("v", 3)
 v(i, j, k).assign(If(u(i + 4, j - 4, k + 4) > u(i - 4, j + 1, k - 2), lo(u(i, j + 4, k), u(i, j, k - 4)), u(i - 1, j, k) * u(i, j, k)))
 STENCIL = [v]
 """,
+    # star-shaped beyond radius 1 (finite-difference scripts of higher order with limiters): the star kernel's cell update when compiled
+    "star2": EXPR_HEAD + """
+lo = Func("min", 2); mag = Func("fabs", 1)
+u = Grid("u", 3); v = Grid("v", 3)
+d4 = lambda a, b, c, d: (8.0 * (c - b) - (d - a)) / 12.0
+gx = d4(u(i - 2, j, k), u(i - 1, j, k), u(i + 1, j, k), u(i + 2, j, k))
+gy = d4(u(i, j - 2, k), u(i, j - 1, k), u(i, j + 1, k), u(i, j + 2, k))
+gz = d4(u(i, j, k - 2), u(i, j, k - 1), u(i, j, k + 1), u(i, j, k + 2))
+v(i, j, k).assign(u(i, j, k) - ConstRef("cfl") * (lo(mag(gx), mag(gy)) + If(gz > 0, gz, 0.5 * gz)))
+STENCIL = [v]
+""",
+    "star4": EXPR_HEAD + """
+hi = Func("max", 2)
+u = Grid("u", 3); v = Grid("v", 3)
+v(i, j, k).assign(hi(u(i + 4, j, k) - u(i - 3, j, k), u(i, j - 4, k) * u(i, j + 3, k)) + u(i, j, k + 4) - 0.5 * u(i, j, k - 4) + u(i, j, k))
+STENCIL = [v]
+""",
     # division and square root
     "norm": EXPR_HEAD + """
 root = Func("sqrt", 1)
@@ -983,7 +1000,7 @@ STENCIL = [v]
 }
 
 
-@pytest.mark.parametrize("case", ["cond", "limiter", "norm", "far3", "far4"])
+@pytest.mark.parametrize("case", ["cond", "limiter", "norm", "far3", "far4", "star2", "star4"])
 def test_stencil_given_as_expression(oracle, dev, case):
     """brk_stencil_apply_expr (non-linear scripts: Func / If / products, what stencils/cond.py is made of): list (with
     skipped entries) and range forms against the oracle's evaluation of the same tree with the accessor's neighbour semantics.  The
@@ -997,8 +1014,8 @@ def test_stencil_given_as_expression(oracle, dev, case):
     assert not spec.linear
 
     def agree(got, want):
-        if case == "norm":
-            assert np.abs(got - want).max() <= 4e-16 * np.abs(want).max() and np.abs(want).max() > 1
+        if case in ("norm", "star2"):      # division / square root: within 2 ulp of the host's
+            assert np.abs(got - want).max() <= 4e-16 * max(1.0, np.abs(want).max()) and np.abs(want).max() > 0.4
         else:
             assert np.array_equal(got, want) and np.unique(want).size > 1000
 
@@ -1020,10 +1037,10 @@ def test_stencil_given_as_expression(oracle, dev, case):
     sc = bl.BrickStorage.allocate(info.nbricks, 512, dev)
     ck.apply(bl.Brick(info, st, 0), bl.Brick(info, sc, 0), ids=grid_to_device(lst, dev))
     star = all(sum(1 for x in o["offset"] if x) <= 1 for o in spec.program(consts)[0])       # every tap on one axis
-    # star-shaped of radius 1: the 7-point kernel k_s7_wg around the program; other stars: the star staging; else the cube tile
-    form = ",s7,list" if star and spec.radius == 1 else (",star" if star else "")
-    assert bl.last_kernel() == "k_expr_jit<%d%s>" % (spec.radius, form) and star == (case in ("cond", "norm"))
-    assert torch.equal(sc.dat, so.dat) and ("brk_user_point7" if form.startswith(",s7") else "brick_apply_star_fn" if star else "brick_apply_fn<") in ck.source
+    # star-shaped of radius 1: the 7-point kernel k_s7_wg around the program; other stars: the star kernel k_star_wg; else the cube tile
+    form = ",s7,list" if star and spec.radius == 1 else (",star_wg" if star else "")
+    assert bl.last_kernel() == "k_expr_jit<%d%s>" % (spec.radius, form) and star == (case in ("cond", "norm", "star2", "star4"))
+    assert torch.equal(sc.dat, so.dat) and ("brk_user_point7" if form.startswith(",s7") else "brk_user_star" if star else "brick_apply_fn<") in ck.source
     if case == "cond":
         sb = bl.BrickStorage.allocate(info.nbricks, 512, dev)
         bl.apply_stencil("cond", bl.Brick(info, st, 0), bl.Brick(info, sb, 0), ids=grid_to_device(lst, dev), coeff=coeff)

@@ -213,8 +213,9 @@ def test_expression_source_generation_and_compilation_without_a_device():
     text = expr_source(s, {"lim": 0.75})
     ops, result = s.program({"lim": 0.75})
     assert text.count(";\n    r") + 1 >= len(ops) and f"return r{result};" in text
-    # every grid reference of this script moves along one axis: the star staging (ti / tj / ck), not the cube tile
-    assert "brklib::brick_apply_star_fn<2>(" in text and "tj[-16]" in text and "ck[2]" in text and "ti[-1]" in text and "0x1.8p-1" in text
+    # every grid reference of this script moves along one axis (radius 2): the cell update of the star kernel k_star_wg, not the cube tile
+    assert "brk_user_star(const double *ck" in text and "jm[1]" in text and "ck[2]" in text and "im[0]" in text and "0x1.8p-1" in text
+    assert "template __global__ void k_star_wg<kStarUser2, 4, 4>(" in text
     assert "__builtin_sqrt(" in text
     cube = expr_source(load_spec(PRELUDE + NONLINEAR[1].replace("g(i + 1, j, k)", "g(i + 1, j - 2, k)")))
     assert "brklib::brick_apply_fn<2>(" in cube and "c[brklib::tap_rel<2>(1, -2, 0)]" in cube
@@ -271,6 +272,6 @@ def test_compiled_form_takes_longer_programs_than_the_interpreter():
     with pytest.raises(ValueError, match="at most %d" % MAX_OPS):
         s.program()
     ops, _ = s.program(max_ops=MAX_OPS_COMPILED)
-    assert MAX_OPS < len(ops) <= MAX_OPS_COMPILED and "brick_apply_star_fn<2>" in expr_source(s)
+    assert MAX_OPS < len(ops) <= MAX_OPS_COMPILED and "brk_user_star(" in expr_source(s)
     with pytest.raises(ValueError, match="at most %d" % MAX_OPS_COMPILED):
         load_spec(PRELUDE + body % 200).program(max_ops=MAX_OPS_COMPILED)

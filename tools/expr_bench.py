@@ -81,6 +81,23 @@ def main():
     timed("radius-2 limiter, interpreted", lambda: bl.apply_expr(lim, A, B, ids=ids, interpret=True))
     c2 = bl.CompiledExpr(lim)
     timed("radius-2 limiter, compiled", lambda: c2.apply(A, B, ids=ids))
+    s2 = load_spec(HEAD + """
+lo = Func("min", 2); mag = Func("fabs", 1)
+d4 = lambda a, b, c, d: (8.0 * (c - b) - (d - a)) / 12.0
+gx = d4(u(i - 2, j, k), u(i - 1, j, k), u(i + 1, j, k), u(i + 2, j, k))
+gy = d4(u(i, j - 2, k), u(i, j - 1, k), u(i, j + 1, k), u(i, j + 2, k))
+gz = d4(u(i, j, k - 2), u(i, j, k - 1), u(i, j, k + 1), u(i, j, k + 2))
+v(i, j, k).assign(u(i, j, k) - 0.3 * (lo(mag(gx), mag(gy)) + If(gz > 0, gz, 0.5 * gz)))
+STENCIL = [v]
+""")
+    cs2 = bl.CompiledExpr(s2)
+    timed("radius-2 STAR limiter (4th-order slopes), compiled", lambda: cs2.apply(A, B, ids=ids))
+    timed("built-in 13-point star, same list", lambda: bl.apply_stencil("mpi13pt", A, B, ids=ids))
+    l13 = load_spec(HEAD + "acc = 0.3 * u(i, j, k)\nfor d in (1, 2):\n  for s in (1, -1):\n    acc = acc + (0.1 / d) * u(i + s * d, j, k) + (0.08 / d) * u(i, j + s * d, k) + (0.06 / d) * u(i, j, k + s * d)\nv(i, j, k).assign(acc)\nSTENCIL = [v]\n")
+    c13 = bl.CompiledExpr(l13)
+    timed("13-point star with its own weights, compiled", lambda: c13.apply(A, B, ids=ids))
+    t13 = l13.taps()
+    timed("the same 13 taps, tap path (k_star_taps)", lambda: bl.apply_taps(t13, A, B, ids=ids))
     # beyond the 125-point cube: (8 + 2R)^3 tiles, 2 / 1 waves per workgroup
     import itertools
     for r in (2, 3, 4):
