@@ -399,6 +399,12 @@ _BUILTIN = {
 }
 
 
+# the constants of the reference's MPI stencils (stencils/fake.h:11-33): what the built-in kernels compute with
+MPI_DEFAULTS = {"MPI_ALPHA": 0.4, "MPI_BETA": 0.1, "MPI_B0": 0.4, "MPI_B1": 0.07, "MPI_B2": 0.03,
+                "MPI_A0": 0.1, "MPI_A1": 0.06, "MPI_A2": 0.045, "MPI_A3": 0.03, "MPI_A4": 0.015,
+                **{f"MPI_C{q}": v for q, v in enumerate((0.1, 0.04, 0.03, 0.01, 0.006, 0.004, 0.005, 0.002, 0.003, 0.001))}}
+
+
 def load_spec(source, filename="<stencil script>"):
     """source: the text of a stencil script (or a path to one).  Returns a Spec."""
     if "\n" not in source and source.endswith(".py"):

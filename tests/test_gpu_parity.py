@@ -1251,6 +1251,60 @@ bl.finalize()
     assert third == (0, first[1]) and os.path.getsize(tmp_path / files[0]) > 4000
 
 
+def test_apply_script_dispatch(oracle, dev):
+    """apply_script: a script that IS one of the reference's stencils runs its tuned kernel, the same script with another constant is
+    compiled (into the tuned star kernel), a 19-point off-axis script is compiled onto the cube tile, 343 taps go to the tap table,
+    a non-linear script is compiled -- each against the oracle"""
+    from test_spec import star_script
+    from bricklib_amd.spec import load_spec
+    ex = os.path.join(ROOT, "examples")
+    grid, info = bl.init_grid((6, 6, 6), dev)
+    ids = np.ascontiguousarray(grid.reshape(6, 6, 6)[1:-1, 1:-1, 1:-1]).reshape(-1)
+    ids_dev = grid_to_device(ids, dev)
+    st, so = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(2))
+    st.dat.uniform_(-0.5, 0.5)
+    hin = st.dat.cpu().numpy()
+    A, B = bl.Brick(info, st, 0), bl.Brick(info, so, 0)
+    coeff = oracle.coeffs(129, 1)
+
+    def check(path, want_path, kernel_prefix, want):
+        assert path == want_path and bl.last_kernel().startswith(kernel_prefix), (path, bl.last_kernel())
+        assert np.abs(so.dat.cpu().numpy() - want).max() <= TOL * 4 and np.abs(want).max() > 0.01
+        so.dat.zero_()
+
+    def by_taps(spec, consts):
+        want = np.zeros_like(hin)
+        oracle.brick_taps(info.adj_host, hin, want, 512, ids, spec.taps(consts))
+        return want
+    from bricklib_amd.spec import MPI_DEFAULTS
+    s13 = load_spec(star_script(2, ["MPI_B0", "MPI_B1", "MPI_B2"]))
+    want = np.zeros_like(hin)
+    oracle.brick_stencil(ST_MPI13, info.adj_host, hin, want, 512, ids=ids)
+    check(bl.apply_script(s13, A, B, ids=ids_dev), "builtin:mpi13pt", "k_star_", want)
+    other = dict(MPI_DEFAULTS, MPI_B1=0.08)
+    check(bl.apply_script(s13, A, B, ids=ids_dev, constants={"MPI_B1": 0.08}), "compiled", "k_expr_jit<2,star_wg>", by_taps(s13, other))
+    s7 = load_spec(star_script(1, ["coeff[0]", "coeff[1]"]).replace("c[1] * src(i + 1, j, k)", "c[1] * src(i + 1, j, k)"))
+    check(bl.apply_script(s7, A, B, ids=ids_dev, constants={"coeff": coeff}), "compiled", "k_expr_jit<1,s7,list>", by_taps(s7, {"coeff": coeff}))
+    seven = load_spec(EXPR_HEAD + """
+u = Grid("bIn", 3); v = Grid("bOut", 3)
+c = [ConstRef("coeff[%d]" % q) for q in range(7)]
+v(i, j, k).assign(c[0] * u(i, j, k) + c[1] * u(i + 1, j, k) + c[2] * u(i - 1, j, k) + c[3] * u(i, j + 1, k) + c[4] * u(i, j - 1, k) +
+                  c[5] * u(i, j, k + 1) + c[6] * u(i, j, k - 1))
+STENCIL = [v]
+""")
+    want = np.zeros_like(hin)
+    oracle.brick_stencil(ST_7PT_COEFF, info.adj_host, hin, want, 512, ids=ids, coeff=coeff)
+    check(bl.apply_script(seven, A, B, ids=ids_dev, constants={"coeff": coeff}), "builtin:7pt", "k_s7_wg<kCoeff", want)
+    lap = load_spec(os.path.join(ex, "lap19.py"))
+    check(bl.apply_script(lap, A, B, ids=ids_dev, constants={"coeff": coeff}), "compiled", "k_expr_jit<1>", by_taps(lap, {"coeff": coeff}))
+    blur = load_spec(os.path.join(ex, "blur343.py"))
+    check(bl.apply_script(blur, A, B, ids=ids_dev, constants={"coeff": coeff}), "taps", "k_taps_far<3,2>", by_taps(blur, {"coeff": coeff}))
+    mm = load_spec(os.path.join(ex, "minmod.py"))
+    want = np.zeros_like(hin)
+    oracle.brick_expr(mm, info.adj_host, hin, want, 512, ids, {"coeff": coeff})
+    check(bl.apply_script(mm, A, B, brick_range=None, ids=ids_dev, constants={"coeff": coeff}), "compiled", "k_expr_jit<1,s7,list>", want)
+
+
 def test_expression_argument_checks(dev):
     """a program is checked before anything is launched: unknown codes, registers out of range or read before written, taps
     outside the 125-point cube, too many operations"""
