@@ -423,6 +423,8 @@ extern "C" int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj, con
   if (!k->fn) return brk_fail(BRK_EINVAL, "the kernel was unloaded by brk_finalize: compile the program again");
   if (!adj || !in || !out || in == out) return brk_fail(BRK_EINVAL, "bad device pointers");
   if (step < 512) return brk_fail(BRK_EINVAL, "step_elems %zu < 512", step);
+  // the tuned kernels a star-shaped program is compiled into move halo rows in 16-byte lanes (as for the built-in stencils)
+  if (((uintptr_t)in | (uintptr_t)out) % 16 || step % 2) return brk_fail(BRK_EINVAL, "brick fields must be 16-byte aligned (in %p, out %p, step_elems %zu)", (const void *)in, (void *)out, step);
   if (n == 0) return BRK_OK;
   hipError_t e;
   if (k->s7()) { // k_s7_wg<kUser, 8, list / range>: eight bricks per workgroup, (adj, in, out, step, ids, first, n, Box, Coeffs, regmask, faces)
