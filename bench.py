@@ -113,6 +113,7 @@ def parse():
                     help="weak workload, deep schedule: the last sweep writes the surface first and the next exchange starts under the rest of that pass "
                          "(+0.2 ms of exchange hidden for +2.5 %% of the cycle); auto = chosen with the schedule from the measured exchange time")
     ap.add_argument("--no-weak-prediction", action="store_true", help="single workload: skip the emulated-exchange rows (predicted_weak_efficiency) behind weak_workload_on_this_gpu")
+    ap.add_argument("--no-scripts", action="store_true", help="single workload: skip the stencil-scripts-as-data lines (stencil_scripts: tuned / compiled / interpreted)")
     ap.add_argument("--no-config3", action="store_true", help="single workload: skip the 27-/125-/13-/25-point lines on the same grid")
     return ap.parse_args()
 
@@ -198,6 +199,59 @@ def cpu_baseline_reference(n_cells_axis, seconds, stencil="7pt", coeff=None):
             "protocol": "time_func (stencils/stencils.h:40-53), TOT_TIME = %.0f s" % seconds,
             "sample": f"{calls} calls over a {stride}^3 array: {points} points updated per call incl. the ghost zone it also sweeps, "
                       f"{n_cells_axis}^3 of them useful (value counts only those), OpenMP {cores} threads, {dt:.1f} s"}
+
+
+COND_SHAPED_SCRIPT = """
+from st.expr import Index, ConstRef, If
+from st.grid import Grid
+from st.func import Func
+i = Index(0); j = Index(1); k = Index(2)
+pos = Func("max", 2)
+u = Grid("bIn", 3); v = Grid("bOut", 3)
+total = None
+for q, (di, dj, dk) in ((5, (0, 0, 1)), (6, (0, 0, -1)), (3, (0, 1, 0)), (4, (0, -1, 0)), (1, (1, 0, 0)), (2, (-1, 0, 0)), (0, (0, 0, 0))):
+    term = ConstRef("coeff[%d]" % q) * pos(u(i + di, j + dj, k + dk), 0.0)
+    total = term if total is None else total + term
+v(i, j, k).assign(If(total > 0, total, -total))
+STENCIL = [v]
+"""
+
+
+def script_lines(bl, info, st, sto, step_e, off_out, ids, stream, launches=40):
+    """ms per sweep of a cond-shaped script over the brick list `ids` (tiled order): tuned kernel, compiled at run time, interpreted"""
+    from bricklib_amd.brick import grid_to_device
+    from bricklib_amd.order import tiled
+    from bricklib_amd.spec import load_spec
+    spec = load_spec(COND_SHAPED_SCRIPT)
+    coeff = np.random.default_rng(1).random(129) - 0.45
+    g3 = np.asarray(ids).reshape(-1)
+    n = round(g3.size ** (1.0 / 3.0))
+    lst = grid_to_device(tiled(g3.reshape(n, n, n)) if n * n * n == g3.size else g3, st.dat.device)
+    bIn, bOut = bl.Brick(info, st, 0), bl.Brick(info, sto, off_out)
+    t0 = time.time()
+    ck = bl.CompiledExpr(spec, {"coeff": coeff})
+    compile_s = time.time() - t0
+    out = {"script": "|sum_t c_t * max(in_t, 0)| over the 7-point star (the shape of stencils/cond.py), given as text at run time",
+           "brk_expr_compile_s": compile_s, "from_disk_cache": ck.from_disk}
+
+    def timed(fn, reps):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        cells = float(g3.size) * 512.0
+        return {"kernel_ms": ms, "GStencil/s": cells / (ms * 1e-3) / 1e9, "roofline_frac": BYTES_PER_UPDATE * cells / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "kernel": bl.last_kernel()}
+    out["tuned_d3cond_kernel"] = timed(lambda: bl.apply_stencil("cond", bIn, bOut, ids=lst, coeff=coeff, stream=stream), launches)
+    out["compiled_at_run_time"] = timed(lambda: ck.apply(bIn, bOut, ids=lst, stream=stream), launches)
+    out["interpreted"] = timed(lambda: bl.apply_expr(spec, bIn, bOut, ids=lst, constants={"coeff": coeff}, stream=stream, interpret=True), 5)
+    ck.release()
+    return out
 
 
 def side_stencil(bl, O, name, info, st, sto, step_e, off_out, ids, box, stream, launches=100, nsample=512, warm_ms=150.0, zigzag=False):
@@ -466,6 +520,14 @@ def run_single(args, bl, dev):
         except Exception:
             pass
         extra["config3"] = {"workload": "single-{27pt,mpi125pt}-%d (+ 13/25-point), same box entry point" % N, **blk}
+    if not args.no_scripts and args.form == "box":
+        # stencil scripts held as DATA by the host, on the same grid, outside the headline: a script of the shape of the
+        # reference's stencils/cond.py compiled at run time (hiprtc; star-shaped of radius 1 -> the headline kernel around the program)
+        # beside the tuned d3cond kernel, and the interpreter.  Never fails the bench: a missing compiler is reported as such.
+        try:
+            extra["stencil_scripts"] = script_lines(bl, info, st, sto, step_e, off_out, ids, stream)
+        except Exception as e:
+            extra["stencil_scripts"] = {"error": repr(e)[:300]}
     if not args.no_cpu_baseline:
         # cpu_baseline = the reference's own CPU code (kind "reference"; built for 512^3 7-point sweeps where /root/reference was
         # present); cpu_baseline_port = the brick-layout restatement (kind "port") beside it.  Where the reference leg is not

@@ -1507,6 +1507,12 @@ def test_bench_line_contract_small():
         assert d["config3"][nm]["max_abs_err_vs_oracle"] <= TOL and d["config3"][nm]["roofline"]["frac"] > 0
         assert d["config3"][nm]["kernel_ms_one_way"] == d["config3"][nm]["kernel_ms"] and d["config3"][nm]["kernel_ms_alternating"] > 0
     assert d["weak_workload_on_this_gpu"]["value"] > 0
+    # round 5: stencil scripts given as data -- the tuned kernel, the run-time compiled kernel (star-shaped, radius 1: k_s7_wg around the
+    # program) and the interpreter, and the fp64-vector roofline beside the HBM one
+    sc = d["stencil_scripts"]
+    assert sc["compiled_at_run_time"]["kernel"] == "k_expr_jit<1,s7,list>" and sc["interpreted"]["kernel"] == "k_expr<1,4>"
+    assert sc["compiled_at_run_time"]["kernel_ms"] < sc["interpreted"]["kernel_ms"] and sc["tuned_d3cond_kernel"]["GStencil/s"] > 0
+    assert d["config3"]["mpi125pt"]["roofline_fp64_vector"]["flop_per_point"] == 134
     # round 4: every sweep walks the bricks in the same direction by default (value / roofline.frac are HBM numbers); the launches
     # with alternating directions (Infinity-Cache re-reads of the input) are timed beside the headline, --alternate swaps the roles
     assert d["config"]["sweep_direction"] == "one way" and d["alternating"]["kernel_ms"] > 0 and d["alternating"]["value"] > 0 and "one_way" not in d

@@ -7,7 +7,7 @@ tag=$1; shift
 mkdir -p gpurun_out/pmc_$tag
 run() { # name counters...
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag/$name -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-weak-reference --steady-seconds 0 --windows 1 $BENCH_ARGS > gpurun_out/pmc_$tag/$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d gpurun_out/pmc_$tag/$name -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-weak-reference --no-scripts --steady-seconds 0 --windows 1 $BENCH_ARGS > gpurun_out/pmc_$tag/$name.log 2>&1
   rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "$name killed"; exit 1; fi
 }
 BENCH_ARGS="$*"
