@@ -27,7 +27,7 @@
 #include "brk_internal.h"
 
 namespace {
-#include "brk_jit_headers.inc" // kJitDeviceHeader (brick-device.h), kJitAbiHeader (brk.h), kJitSbaseHeader (brk_sbase.h), kJitStar7Header (brk_star7_kernel.h), kJitStarWgHeader (brk_starwg_kernel.h)
+#include "brk_jit_headers.inc" // kJitDeviceHeader (brick-device.h), kJitAbiHeader (brk.h), kJitSbaseHeader (brk_sbase.h), kJitStar7Header (brk_star7_kernel.h), kJitStarWgHeader (brk_starwg_kernel.h), kJitCubeHeader (brk_cubedense_kernel.h)
 
 struct Rtc {
   void *handle = nullptr;
@@ -102,6 +102,9 @@ const char kS7Range[] = "_ZN6brklib3jit7k_s7_wgILi3ELi8ELi0ELi0ELi0EEEvPKjPKdPdm
 // (radius 2 at four groups per CU; five, like the built-in 13-point kernel, measured the same for a 13-tap program: 0.477 vs 0.475 ms)
 const char kSw2[] = "_ZN6brklib3jit9k_star_wgILi5ELi4ELi4ELi0EEEvPKjPKdPdmS3_jjNS_6CoeffsES3_";
 const char kSw4[] = "_ZN6brklib3jit9k_star_wgILi6ELi4ELi3ELi0EEEvPKjPKdPdmS3_jjNS_6CoeffsES3_";
+
+// ... and a program of radius 1 that is not star-shaped: k_cube_dense<kCubeUser1, 4, 4, 1> of brk_cubedense_kernel.h
+const char kCube1[] = "_ZN6brklib3jit12k_cube_denseILi3ELi4ELi4ELi1EEEvPKjPKdPdmS3_jjNS_6CoeffsEiS3_S3_jj";
 
 void statement_rhs(const brk_expr_op &o, const char *tap, char (&rhs)[160]) {
   char a[16], b[16], c[16];
@@ -196,9 +199,34 @@ std::string generate_sw(const brk_expr_op *ops, uint32_t nops, uint32_t result, 
   return s;
 }
 
+// A program of radius 1 with taps off the axes (mixed derivatives, Moore-neighbourhood rules, 19- / 27-point operators with limiters):
+// the 27-point kernel's machinery -- dense bank-conflict-free tiles, i-halo columns out of the sibling waves' tiles, exact links, 16-byte
+// staging -- around the program as its cell update.
+std::string generate_cube1(const brk_expr_op *ops, uint32_t nops, uint32_t result) {
+  std::string s = "// generated by brk_expr_compile (bricklib_amd/csrc/brk_jit.hip): the program as the cell update of k_cube_dense\n";
+  s += kTypedefs;
+  s += "#define BRK_JIT_CUBE\n#include \"brk_cubedense_kernel.h\"\nnamespace brklib {\nnamespace jit {\n"
+       "__device__ __forceinline__ double brk_user_cube(const double *c, const int *col) {\n";
+  s += declare_registers(ops, nops);
+  char buf[256], rhs[160], tap[48];
+  for (uint32_t t = 0; t < nops; ++t) {
+    const brk_expr_op &o = ops[t];
+    snprintf(tap, sizeof tap, "c[%d + col[%d]]", o.offset[2] * 80 + o.offset[1] * 8, o.offset[0]); // plane pitch 10 rows x 8, row pitch 8
+    statement_rhs(o, tap, rhs);
+    snprintf(buf, sizeof buf, "    r%u = %s;\n", o.dst, rhs);
+    s += buf;
+  }
+  snprintf(buf, sizeof buf, "    return r%u;\n}\n", result);
+  s += buf;
+  s += "template __global__ void k_cube_dense<kCubeUser1, 4, 4, 1>(const uint32_t *, const double *, double *, size_t, const uint32_t *, uint32_t, uint32_t, Coeffs, int, const uint32_t *, const uint32_t *, uint32_t, uint32_t);\n"
+       "} // namespace jit\n} // namespace brklib\n";
+  return s;
+}
+
 std::string generate(const brk_expr_op *ops, uint32_t nops, uint32_t result, int R) {
   std::string s;
   const bool star = star_shaped(ops, nops);
+  if (!star && R == 1) return generate_cube1(ops, nops, result);
   if (star && R == 1) return generate_s7(ops, nops, result);
   if (star) return generate_sw(ops, nops, result, R == 2 ? 2 : 4); // radius 3 runs on the radius-4 kernel
   s += "// generated by brk_expr_compile (bricklib_amd/csrc/brk_jit.hip)\n";
@@ -330,7 +358,7 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   auto load = [](brk_expr_kernel *k) -> int {
     hipError_t e = hipModuleLoadData(&k->module, k->code.data());
     if (e != hipSuccess) return brk_fail(BRK_EHIP, "hipModuleLoadData: %s", hipGetErrorString(e));
-    e = hipModuleGetFunction(&k->fn, k->module, k->s7() ? kS7List : (k->star ? (k->radius == 2 ? kSw2 : kSw4) : "k_expr_jit"));
+    e = hipModuleGetFunction(&k->fn, k->module, k->s7() ? kS7List : (k->star ? (k->radius == 2 ? kSw2 : kSw4) : (k->radius == 1 ? kCube1 : "k_expr_jit")));
     if (e == hipSuccess && k->s7()) e = hipModuleGetFunction(&k->fn_range, k->module, kS7Range);
     if (e != hipSuccess) {
       (void)hipModuleUnload(k->module);
@@ -351,7 +379,7 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   // covers everything the code depends on: generated text, the two embedded headers, target, options
   std::string disk;
   if (const char *dir = getenv("BRK_JIT_CACHE_DIR"); dir && *dir && have_device) {
-    static const uint64_t hdr_hash = fnv(kJitStarWgHeader, sizeof kJitStarWgHeader, fnv(kJitStar7Header, sizeof kJitStar7Header, fnv(kJitSbaseHeader, sizeof kJitSbaseHeader, fnv(kJitAbiHeader, sizeof kJitAbiHeader, fnv(kJitDeviceHeader, sizeof kJitDeviceHeader)))));
+    static const uint64_t hdr_hash = fnv(kJitCubeHeader, sizeof kJitCubeHeader, fnv(kJitStarWgHeader, sizeof kJitStarWgHeader, fnv(kJitStar7Header, sizeof kJitStar7Header, fnv(kJitSbaseHeader, sizeof kJitSbaseHeader, fnv(kJitAbiHeader, sizeof kJitAbiHeader, fnv(kJitDeviceHeader, sizeof kJitDeviceHeader))))));
     const uint64_t h1 = fnv(arch, std::strlen(arch), fnv(src.data(), src.size(), hdr_hash)), h2 = fnv(src.data(), src.size(), 0x9e3779b97f4a7c15ull ^ hdr_hash);
     char name[96];
     snprintf(name, sizeof name, "/brk_expr_%016llx%016llx.co", (unsigned long long)h1, (unsigned long long)h2);
@@ -377,9 +405,9 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   Rtc *rt = rtc();
   if (!rt) return brk_fail(BRK_ENODEV, "%s (brk_stencil_apply_expr runs a program without a compiler)", rtc_state().why);
   hiprtcProgram prog = nullptr;
-  const char *hdr[] = {kJitDeviceHeader, kJitAbiHeader, kJitSbaseHeader, kJitStar7Header, kJitStarWgHeader};
-  const char *names[] = {"brick-device.h", "brk.h", "brk_sbase.h", "brk_star7_kernel.h", "brk_starwg_kernel.h"};
-  hiprtcResult r = rt->Create(&prog, src.c_str(), "k_expr_jit.hip", 5, hdr, names);
+  const char *hdr[] = {kJitDeviceHeader, kJitAbiHeader, kJitSbaseHeader, kJitStar7Header, kJitStarWgHeader, kJitCubeHeader};
+  const char *names[] = {"brick-device.h", "brk.h", "brk_sbase.h", "brk_star7_kernel.h", "brk_starwg_kernel.h", "brk_cubedense_kernel.h"};
+  hiprtcResult r = rt->Create(&prog, src.c_str(), "k_expr_jit.hip", 6, hdr, names);
   if (r != HIPRTC_SUCCESS) return brk_fail(BRK_EHIP, "hiprtcCreateProgram: %s", rt->ErrorString(r));
   // -ffp-contract=off: a script's `a * b + c` stays two roundings, as in the interpreter and in the checker
   const char *opts[] = {arch, "-O3", "-std=c++17", "-ffp-contract=off"};
@@ -448,6 +476,16 @@ extern "C" int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj, con
     brki_note_kernel(k->radius == 2 ? "k_expr_jit<2,star_wg>" : (k->radius == 3 ? "k_expr_jit<3,star_wg>" : "k_expr_jit<4,star_wg>"));
     e = hipModuleLaunchKernel(k->fn, wgs, 1, 1, 256, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
     brki_adj_unlock();
+  } else if (k->radius == 1) { // k_cube_dense<kCubeUser1, 4, 4, 1>: (adj, in, out, step, ids, first, n, Coeffs, diag, linkmask, cubemask, cs1, cs2)
+    brklib::Coeffs cf;
+    std::memset(&cf, 0, sizeof cf);
+    int diag = 0;
+    const uint32_t *none = nullptr;
+    uint32_t zero = 0;
+    const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
+    void *args[] = {&adj, &in, &out, &step, &ids, &first, &n, &cf, &diag, &none, &none, &zero, &zero};
+    brki_note_kernel("k_expr_jit<1,cube_dense>");
+    e = hipModuleLaunchKernel(k->fn, wgs, 1, 1, 256, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
   } else {
     const uint32_t wpw = waves_per_group(k->radius, k->star);
     const uint32_t wgs = (((n + wpw - 1) / wpw + 7) / 8) * 8;

@@ -19,7 +19,8 @@ cd "$OUT"
   echo 'const char kJitAbiHeader[] = R"BRKSRC('; cat "$ROOT/include/brk.h"; echo ')BRKSRC";'
   echo 'const char kJitSbaseHeader[] = R"BRKSRC('; cat "$ROOT/bricklib_amd/csrc/brk_sbase.h"; echo ')BRKSRC";'
   echo 'const char kJitStar7Header[] = R"BRKSRC('; cat "$ROOT/bricklib_amd/csrc/brk_star7_kernel.h"; echo ')BRKSRC";'
-  echo 'const char kJitStarWgHeader[] = R"BRKSRC('; cat "$ROOT/bricklib_amd/csrc/brk_starwg_kernel.h"; echo ')BRKSRC";'; } > brk_jit_headers.inc
+  echo 'const char kJitStarWgHeader[] = R"BRKSRC('; cat "$ROOT/bricklib_amd/csrc/brk_starwg_kernel.h"; echo ')BRKSRC";'
+  echo 'const char kJitCubeHeader[] = R"BRKSRC('; cat "$ROOT/bricklib_amd/csrc/brk_cubedense_kernel.h"; echo ')BRKSRC";'; } > brk_jit_headers.inc
 INC="-I$OUT $INC"
 pids=()
 for f in brk_kernels brk_star7 brk_starwg brk_cubedense brk_cube125q brk_place brk_exchange brk_jit; do

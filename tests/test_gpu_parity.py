@@ -1038,7 +1038,7 @@ def test_stencil_given_as_expression(oracle, dev, case):
     ck.apply(bl.Brick(info, st, 0), bl.Brick(info, sc, 0), ids=grid_to_device(lst, dev))
     star = all(sum(1 for x in o["offset"] if x) <= 1 for o in spec.program(consts)[0])       # every tap on one axis
     # star-shaped of radius 1: the 7-point kernel k_s7_wg around the program; other stars: the star kernel k_star_wg; else the cube tile
-    form = ",s7,list" if star and spec.radius == 1 else (",star_wg" if star else "")
+    form = ",s7,list" if star and spec.radius == 1 else (",star_wg" if star else (",cube_dense" if spec.radius == 1 else ""))
     assert bl.last_kernel() == "k_expr_jit<%d%s>" % (spec.radius, form) and star == (case in ("cond", "norm", "star2", "star4"))
     assert torch.equal(sc.dat, so.dat) and ("brk_user_point7" if form.startswith(",s7") else "brk_user_star" if star else "brick_apply_fn<") in ck.source
     if case == "cond":
@@ -1296,7 +1296,7 @@ STENCIL = [v]
     oracle.brick_stencil(ST_7PT_COEFF, info.adj_host, hin, want, 512, ids=ids, coeff=coeff)
     check(bl.apply_script(seven, A, B, ids=ids_dev, constants={"coeff": coeff}), "builtin:7pt", "k_s7_wg<kCoeff", want)
     lap = load_spec(os.path.join(ex, "lap19.py"))
-    check(bl.apply_script(lap, A, B, ids=ids_dev, constants={"coeff": coeff}), "compiled", "k_expr_jit<1>", by_taps(lap, {"coeff": coeff}))
+    check(bl.apply_script(lap, A, B, ids=ids_dev, constants={"coeff": coeff}), "compiled", "k_expr_jit<1,cube_dense>", by_taps(lap, {"coeff": coeff}))
     blur = load_spec(os.path.join(ex, "blur343.py"))
     check(bl.apply_script(blur, A, B, ids=ids_dev, constants={"coeff": coeff}), "taps", "k_taps_far<3,2>", by_taps(blur, {"coeff": coeff}))
     mm = load_spec(os.path.join(ex, "minmod.py"))

@@ -81,6 +81,21 @@ def main():
     timed("radius-2 limiter, interpreted", lambda: bl.apply_expr(lim, A, B, ids=ids, interpret=True))
     c2 = bl.CompiledExpr(lim)
     timed("radius-2 limiter, compiled", lambda: c2.apply(A, B, ids=ids))
+    lap = load_spec(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "examples", "lap19.py"))
+    cl19 = bl.CompiledExpr(lap, {"coeff": coeff})
+    timed("lap19.py (19 taps, faces + edges), compiled", lambda: cl19.apply(A, B, ids=ids))
+    t19 = lap.taps({"coeff": coeff})
+    timed("lap19.py, tap path (k_taps)", lambda: bl.apply_taps(t19, A, B, ids=ids))
+    mixed = load_spec(HEAD + """
+hi = Func("max", 2)
+uxy = u(i + 1, j + 1, k) - u(i + 1, j - 1, k) - u(i - 1, j + 1, k) + u(i - 1, j - 1, k)
+uyz = u(i, j + 1, k + 1) - u(i, j + 1, k - 1) - u(i, j - 1, k + 1) + u(i, j - 1, k - 1)
+v(i, j, k).assign(u(i, j, k) + 0.25 * hi(uxy, uyz) * If(uxy * uyz > 0, 1.0, 0.5))
+STENCIL = [v]
+""")
+    cmx = bl.CompiledExpr(mixed)
+    timed("mixed derivatives (radius 1, off-axis, max / If), compiled", lambda: cmx.apply(A, B, ids=ids))
+    timed("built-in 27-point kernel, same list", lambda: bl.apply_stencil("27pt", A, B, ids=ids, coeff=[0.01 * q for q in range(129)]))
     s2 = load_spec(HEAD + """
 lo = Func("min", 2); mag = Func("fabs", 1)
 d4 = lambda a, b, c, d: (8.0 * (c - b) - (d - a)) / 12.0
