@@ -1,6 +1,7 @@
 // brk_cubedense_kernel.h -- the device side of the cube kernel k_cube_dense (brk_cubedense.hip includes it; brk_jit.hip carries it as
 // text so that brk_expr_compile can instantiate the 27-point kernel's machinery -- dense tiles, sibling / fallback slots, exact links --
-// around a user-written cell update: the unit defines brklib::jit::brk_user_cube and instantiates k_cube_dense<kCubeUser1, 4, 4, 1>).
+// around a user-written cell update: the unit defines brklib::jit::brk_user_cube and instantiates k_cube_dense<kCubeUser1, 4, 4, 1> or,
+// for radius 2, <kCubeUser2, 4, 3, 5>).
 // Device code only.
 #ifndef BRK_CUBEDENSE_KERNEL_H
 #define BRK_CUBEDENSE_KERNEL_H
@@ -56,8 +57,8 @@ extern "C" int brk_debug_stamps_by_wave(unsigned long long out[4][8]) {
 #endif
 namespace BRK_CD_NS {
 #ifdef BRK_JIT_CUBE
-// run-time compiled units (brk_expr_compile, programs of radius 1 that are not star-shaped) define the cell update themselves:
-// in[p + (di, dj, dk)] = c[dk * 80 + dj * 8 + col[di]] (c: the cell's row start in its plane of the dense tile, col: per-lane column
+// run-time compiled units (brk_expr_compile, programs of radius 1 or 2 that are not star-shaped) define the cell update themselves:
+// in[p + (di, dj, dk)] = c[dk * (8 + 2R) * 8 + dj * 8 + col[di]] (c: the cell's row start in its plane of the dense tile, col: per-lane column
 // offsets -- own tile, sibling tile or the slot on that side)
 __device__ __forceinline__ double brk_user_cube(const double *c, const int *col);
 #endif
@@ -106,7 +107,7 @@ struct DX {
   // The full radius-2 cube gathers PAIRS of cells: its halo is two columns wide and the edge blocks are rows of eight, so every
   // wanted cell has its i-neighbour (ii ^ 1 counted from the tile's column 0 = ii with R even) wanted too -- 16 bytes per lane,
   // half the gather instructions, and the two cells of a 16-byte segment are no longer requested by different lanes.
-  static constexpr bool PAIR = KIND == kCube125;
+  static constexpr bool PAIR = KIND == kCube125 || KIND == kCubeUser2;
   static constexpr int count(int side) {
     int n = 0;
     for (int kk = 0; kk < T; ++kk)
@@ -159,14 +160,14 @@ constexpr DenseExtra<KIND> make_dense_extra() {
 
 
 __device__ const DenseExtra<kCube27> g_dense27 = make_dense_extra<kCube27>();
+__device__ const DenseExtra<kCube125> g_dense125 = make_dense_extra<kCube125>();
 #ifdef BRK_JIT_CUBE
 template <int KIND>
 __device__ __forceinline__ const uint32_t *dense_table() {
-  static_assert(KIND == kCubeUser1, "a run-time compiled unit instantiates the radius-1 kernel only");
-  return g_dense27.e; // same cells, same slots as the 27-point stencil
+  static_assert(KIND == kCubeUser1 || KIND == kCubeUser2, "a run-time compiled unit instantiates the user kinds only");
+  return KIND == kCubeUser1 ? g_dense27.e : g_dense125.e; // same cells, same slots as the 27- / 125-point stencils
 }
 #else
-__device__ const DenseExtra<kCube125> g_dense125 = make_dense_extra<kCube125>();
 __device__ const DenseExtra<kDiamond25> g_dense_d25 = make_dense_extra<kDiamond25>();
 template <int KIND>
 __device__ __forceinline__ const uint32_t *dense_table() {
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
   constexpr bool W16 = R == 2;
   // the output-side 125-point form reads everything from LDS (no register copy of the brick's own column): the brick and its
   // k-faces are moved in 16-byte lanes too -- lane l of instruction q takes elements 2(l%32), +1 of plane 2q + l/32
-  constexpr bool KF16 = KIND == kCube125 && PIPE == 5; // both planes of a k-face go to LDS: one full-wave instruction per side
+  constexpr bool KF16 = (KIND == kCube125 || KIND == kCubeUser2) && PIPE == 5; // both planes of a k-face go to LDS: one full-wave instruction per side
   // The diamond as well since round 4, but only with the plane loop WITHOUT read-ahead (PIPE 0: 116 VGPRs): with the read-ahead the
   // kernel sits at its 128-register bound, hipcc spills two gathered values and waits for vmcnt(0) in the middle of the fetch phase to
   // store them (0.545 vs 0.430 ms).  8 instead of 15 vector memory instructions per wave: 0.427-0.430 vs 0.430-0.435 ms.
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(64 * NW, OCC) void k_cube_dense(
         else if (PIPE == 5) cube125_accumulate_jout<TL::T * 8, 8>(tile, co, cf, jslot + (PIPE == 5 ? w * 192 : 0), (double *)dst, lane);
         else cube125_accumulate_simple<TL::T * 8, 8>(tile + (hi + R) * 8, co, cf, (double *)dst, lane);
 #ifdef BRK_JIT_CUBE
-      } else if (KIND == kCubeUser1) {
+      } else if (KIND == kCubeUser1 || KIND == kCubeUser2) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) store_result(&dst[k * 64 + lane], brk_user_cube(tile + (k + R) * TL::T * 8 + (hi + R) * 8, col + R));
 #endif

@@ -90,6 +90,11 @@ bool star_shaped(const brk_expr_op *ops, uint32_t nops) {
   return true;
 }
 
+// programs of radius 1 or 2 with taps off the axes go into the cube kernel -- while they are short: its fetch side leaves the compute
+// phase 168 registers at three groups per CU, and a sum of 125 taps written out (501 operations x 8 planes) spills there (8.4 ms
+// against 3.4 on the plain tile; such sums belong to brk_stencil_apply_taps anyway)
+bool cube_form(const brk_expr_op *ops, uint32_t nops, int R) { return !star_shaped(ops, nops) && R <= 2 && nops <= 160; }
+
 // waves per workgroup of the generated kernel = CubeWaves<R> / StarWaves<R> of brick-device.h
 uint32_t waves_per_group(int R, bool star) { return star ? (R <= 2 ? 4u : 2u) : (R <= 2 ? 4u : (R == 3 ? 2u : 1u)); }
 
@@ -105,6 +110,8 @@ const char kSw4[] = "_ZN6brklib3jit9k_star_wgILi6ELi4ELi3ELi0EEEvPKjPKdPdmS3_jjN
 
 // ... and a program of radius 1 that is not star-shaped: k_cube_dense<kCubeUser1, 4, 4, 1> of brk_cubedense_kernel.h
 const char kCube1[] = "_ZN6brklib3jit12k_cube_denseILi3ELi4ELi4ELi1EEEvPKjPKdPdmS3_jjNS_6CoeffsEiS3_S3_jj";
+// ... radius 2, not star-shaped: k_cube_dense<kCubeUser2, 4, 3, 5> (the 125-point kernel's fetch side: everything in 16-byte lanes to LDS)
+const char kCube2[] = "_ZN6brklib3jit12k_cube_denseILi4ELi4ELi3ELi5EEEvPKjPKdPdmS3_jjNS_6CoeffsEiS3_S3_jj";
 
 void statement_rhs(const brk_expr_op &o, const char *tap, char (&rhs)[160]) {
   char a[16], b[16], c[16];
@@ -199,10 +206,10 @@ std::string generate_sw(const brk_expr_op *ops, uint32_t nops, uint32_t result, 
   return s;
 }
 
-// A program of radius 1 with taps off the axes (mixed derivatives, Moore-neighbourhood rules, 19- / 27-point operators with limiters):
-// the 27-point kernel's machinery -- dense bank-conflict-free tiles, i-halo columns out of the sibling waves' tiles, exact links, 16-byte
-// staging -- around the program as its cell update.
-std::string generate_cube1(const brk_expr_op *ops, uint32_t nops, uint32_t result) {
+// A program of radius 1 or 2 with taps off the axes (mixed derivatives, Moore-neighbourhood rules, 19- / 27-point operators with
+// limiters): the 27- / 125-point kernel's machinery -- dense bank-conflict-free tiles, i-halo columns out of the sibling waves' tiles,
+// exact links, 16-byte staging -- around the program as its cell update.
+std::string generate_cube(const brk_expr_op *ops, uint32_t nops, uint32_t result, int R) {
   std::string s = "// generated by brk_expr_compile (bricklib_amd/csrc/brk_jit.hip): the program as the cell update of k_cube_dense\n";
   s += kTypedefs;
   s += "#define BRK_JIT_CUBE\n#include \"brk_cubedense_kernel.h\"\nnamespace brklib {\nnamespace jit {\n"
@@ -211,14 +218,15 @@ std::string generate_cube1(const brk_expr_op *ops, uint32_t nops, uint32_t resul
   char buf[256], rhs[160], tap[48];
   for (uint32_t t = 0; t < nops; ++t) {
     const brk_expr_op &o = ops[t];
-    snprintf(tap, sizeof tap, "c[%d + col[%d]]", o.offset[2] * 80 + o.offset[1] * 8, o.offset[0]); // plane pitch 10 rows x 8, row pitch 8
+    snprintf(tap, sizeof tap, "c[%d + col[%d]]", o.offset[2] * (8 + 2 * R) * 8 + o.offset[1] * 8, o.offset[0]); // plane pitch (8 + 2R) rows x 8, row pitch 8
     statement_rhs(o, tap, rhs);
     snprintf(buf, sizeof buf, "    r%u = %s;\n", o.dst, rhs);
     s += buf;
   }
   snprintf(buf, sizeof buf, "    return r%u;\n}\n", result);
   s += buf;
-  s += "template __global__ void k_cube_dense<kCubeUser1, 4, 4, 1>(const uint32_t *, const double *, double *, size_t, const uint32_t *, uint32_t, uint32_t, Coeffs, int, const uint32_t *, const uint32_t *, uint32_t, uint32_t);\n"
+  s += R == 1 ? "template __global__ void k_cube_dense<kCubeUser1, 4, 4, 1>(" : "template __global__ void k_cube_dense<kCubeUser2, 4, 3, 5>(";
+  s += "const uint32_t *, const double *, double *, size_t, const uint32_t *, uint32_t, uint32_t, Coeffs, int, const uint32_t *, const uint32_t *, uint32_t, uint32_t);\n"
        "} // namespace jit\n} // namespace brklib\n";
   return s;
 }
@@ -226,7 +234,7 @@ std::string generate_cube1(const brk_expr_op *ops, uint32_t nops, uint32_t resul
 std::string generate(const brk_expr_op *ops, uint32_t nops, uint32_t result, int R) {
   std::string s;
   const bool star = star_shaped(ops, nops);
-  if (!star && R == 1) return generate_cube1(ops, nops, result);
+  if (cube_form(ops, nops, R)) return generate_cube(ops, nops, result, R);
   if (star && R == 1) return generate_s7(ops, nops, result);
   if (star) return generate_sw(ops, nops, result, R == 2 ? 2 : 4); // radius 3 runs on the radius-4 kernel
   s += "// generated by brk_expr_compile (bricklib_amd/csrc/brk_jit.hip)\n";
@@ -276,6 +284,7 @@ struct brk_expr_kernel {
   int radius = 1, device = 0;
   bool star = false, from_disk = false;
   bool s7() const { return star && radius == 1; }
+  bool cube = false; // k_cube_dense around the program (cube_form)
   std::string source, code; // generated text; the code object (kept: brk_finalize unloads the module, a later compile of the same program loads it again)
 };
 
@@ -358,7 +367,7 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   auto load = [](brk_expr_kernel *k) -> int {
     hipError_t e = hipModuleLoadData(&k->module, k->code.data());
     if (e != hipSuccess) return brk_fail(BRK_EHIP, "hipModuleLoadData: %s", hipGetErrorString(e));
-    e = hipModuleGetFunction(&k->fn, k->module, k->s7() ? kS7List : (k->star ? (k->radius == 2 ? kSw2 : kSw4) : (k->radius == 1 ? kCube1 : "k_expr_jit")));
+    e = hipModuleGetFunction(&k->fn, k->module, k->s7() ? kS7List : (k->star ? (k->radius == 2 ? kSw2 : kSw4) : (k->cube ? (k->radius == 1 ? kCube1 : kCube2) : "k_expr_jit")));
     if (e == hipSuccess && k->s7()) e = hipModuleGetFunction(&k->fn_range, k->module, kS7Range);
     if (e != hipSuccess) {
       (void)hipModuleUnload(k->module);
@@ -391,7 +400,7 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
       fclose(f);
       if (code.size() > 64 && std::memcmp(code.data(), "\177ELF", 4) == 0) {
         std::unique_ptr<brk_expr_kernel> k(new brk_expr_kernel);
-        k->radius = R, k->device = dev, k->star = star_shaped(ops, nops), k->from_disk = true, k->source = src, k->code = std::move(code);
+        k->radius = R, k->device = dev, k->star = star_shaped(ops, nops), k->cube = cube_form(ops, nops, R), k->from_disk = true, k->source = src, k->code = std::move(code);
         if (load(k.get()) == BRK_OK) {
           *out = k.get();
           Cached &c = cache()[key];
@@ -434,7 +443,7 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
     }
   }
   std::unique_ptr<brk_expr_kernel> k(new brk_expr_kernel);
-  k->radius = R, k->device = dev, k->star = star_shaped(ops, nops), k->source = std::move(src), k->code = std::move(code);
+  k->radius = R, k->device = dev, k->star = star_shaped(ops, nops), k->cube = cube_form(ops, nops, R), k->source = std::move(src), k->code = std::move(code);
   if (int rc = load(k.get())) return rc;
   *out = k.get();
   Cached &c = cache()[key];
@@ -476,7 +485,7 @@ extern "C" int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj, con
     brki_note_kernel(k->radius == 2 ? "k_expr_jit<2,star_wg>" : (k->radius == 3 ? "k_expr_jit<3,star_wg>" : "k_expr_jit<4,star_wg>"));
     e = hipModuleLaunchKernel(k->fn, wgs, 1, 1, 256, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
     brki_adj_unlock();
-  } else if (k->radius == 1) { // k_cube_dense<kCubeUser1, 4, 4, 1>: (adj, in, out, step, ids, first, n, Coeffs, diag, linkmask, cubemask, cs1, cs2)
+  } else if (k->cube) { // k_cube_dense<kCubeUser1, 4, 4, 1> / <kCubeUser2, 4, 3, 5>: (adj, in, out, step, ids, first, n, Coeffs, diag, linkmask, cubemask, cs1, cs2)
     brklib::Coeffs cf;
     std::memset(&cf, 0, sizeof cf);
     int diag = 0;
@@ -484,7 +493,7 @@ extern "C" int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj, con
     uint32_t zero = 0;
     const uint32_t wgs = (((n + 3) / 4 + 7) / 8) * 8;
     void *args[] = {&adj, &in, &out, &step, &ids, &first, &n, &cf, &diag, &none, &none, &zero, &zero};
-    brki_note_kernel("k_expr_jit<1,cube_dense>");
+    brki_note_kernel(k->radius == 1 ? "k_expr_jit<1,cube_dense>" : "k_expr_jit<2,cube_dense>");
     e = hipModuleLaunchKernel(k->fn, wgs, 1, 1, 256, 1, 1, 0, static_cast<hipStream_t>(s), args, nullptr);
   } else {
     const uint32_t wpw = waves_per_group(k->radius, k->star);

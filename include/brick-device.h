@@ -239,12 +239,13 @@ __device__ __forceinline__ const uint32_t *extra_table() {
   return g_extra4.e;
 }
 
-enum CubeKind { kCube27, kCube125, kDiamond25, kCubeUser1 }; // kCubeUser1: a run-time compiled cell update on the 27-point kernel's tiles (brk_expr_compile)
+enum CubeKind { kCube27, kCube125, kDiamond25, kCubeUser1, kCubeUser2 }; // kCubeUser*: run-time compiled cell updates on the 27- / 125-point kernels' tiles (brk_expr_compile)
 template <int KIND> struct CubeTraits;
 template <> struct CubeTraits<kCube27> { static constexpr int R = 1; };
 template <> struct CubeTraits<kCube125> { static constexpr int R = 2; };
 template <> struct CubeTraits<kDiamond25> { static constexpr int R = 2; };
 template <> struct CubeTraits<kCubeUser1> { static constexpr int R = 1; };
+template <> struct CubeTraits<kCubeUser2> { static constexpr int R = 2; };
 
 // Two sweeps of a 7-point star in one pass: S*S has 25 taps, the points within L1 distance 2.  Tap t of the table below has
 // weight Coeffs::c[t]; the launcher fills c[t] = sum over pairs (u, v) of star offsets (incl. 0) with u + v = tap of w(u) w(v).

@@ -1038,9 +1038,9 @@ def test_stencil_given_as_expression(oracle, dev, case):
     ck.apply(bl.Brick(info, st, 0), bl.Brick(info, sc, 0), ids=grid_to_device(lst, dev))
     star = all(sum(1 for x in o["offset"] if x) <= 1 for o in spec.program(consts)[0])       # every tap on one axis
     # star-shaped of radius 1: the 7-point kernel k_s7_wg around the program; other stars: the star kernel k_star_wg; else the cube tile
-    form = ",s7,list" if star and spec.radius == 1 else (",star_wg" if star else (",cube_dense" if spec.radius == 1 else ""))
+    form = ",s7,list" if star and spec.radius == 1 else (",star_wg" if star else (",cube_dense" if spec.radius <= 2 else ""))
     assert bl.last_kernel() == "k_expr_jit<%d%s>" % (spec.radius, form) and star == (case in ("cond", "norm", "star2", "star4"))
-    assert torch.equal(sc.dat, so.dat) and ("brk_user_point7" if form.startswith(",s7") else "brk_user_star" if star else "brick_apply_fn<") in ck.source
+    assert torch.equal(sc.dat, so.dat) and ("brk_user_point7" if form.startswith(",s7") else "brk_user_star" if star else "brk_user_cube" if form else "brick_apply_fn<") in ck.source
     if case == "cond":
         sb = bl.BrickStorage.allocate(info.nbricks, 512, dev)
         bl.apply_stencil("cond", bl.Brick(info, st, 0), bl.Brick(info, sb, 0), ids=grid_to_device(lst, dev), coeff=coeff)
@@ -1086,7 +1086,7 @@ def test_compiled_expression_lifecycle(dev):
     for cfl in (0.3, 0.3, 0.25):
         s2.dat.zero_()
         bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, s2, 0), constants={"cfl": cfl})
-        assert bl.last_kernel() == "k_expr_jit<2>" and torch.equal(s1.dat, s2.dat) == (cfl == 0.3)
+        assert bl.last_kernel() == "k_expr_jit<2,cube_dense>" and torch.equal(s1.dat, s2.dat) == (cfl == 0.3)
     assert len(spec._compiled) == 2 and {k._h.value for k in spec._compiled.values()} == {a._h.value, c._h.value}
     with pytest.raises(BrkError):
         a.apply(bl.Brick(info, st, 0), bl.Brick(info, st, 0))          # in == out

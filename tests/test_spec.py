@@ -218,7 +218,10 @@ def test_expression_source_generation_and_compilation_without_a_device():
     assert "template __global__ void k_star_wg<kStarUser2, 4, 4>(" in text
     assert "__builtin_sqrt(" in text
     cube = expr_source(load_spec(PRELUDE + NONLINEAR[1].replace("g(i + 1, j, k)", "g(i + 1, j - 2, k)")))
-    assert "brklib::brick_apply_fn<2>(" in cube and "c[brklib::tap_rel<2>(1, -2, 0)]" in cube
+    # taps off the axes, radius 2: the cell update of the cube kernel (plane pitch 12 rows x 8)
+    assert "brk_user_cube(const double *c, const int *col)" in cube and "c[-16 + col[1]]" in cube and "k_cube_dense<kCubeUser2, 4, 3, 5>(" in cube
+    far = expr_source(load_spec(PRELUDE + NONLINEAR[1].replace("g(i + 1, j, k)", "g(i + 3, j - 2, k)")))
+    assert "brklib::brick_apply_fn<3>(" in far and "c[brklib::tap_rel<3>(3, -2, 0)]" in far      # beyond radius 2: the (8 + 2R)^3 tile
     assert expr_source(s, {"lim": 0.75}) == text and expr_source(s, {"lim": 0.5}) != text
     # a star-shaped program of radius 1: the 7-point kernel itself, instantiated around the program as its cell update
     seven = expr_source(load_spec(COND_LIKE), {"coeff": [0.1] * 7})
