@@ -101,6 +101,10 @@ class _PlacedMemory:
         self.report = {"candidates": rep.candidates, "chosen": rep.chosen, "probe_bricks": rep.probe_bricks, "spacer_gib": rep.spacer_gib,
                        "probe_sweep_ms_chosen": rep.ms_chosen, "probe_sweep_ms_worst": rep.ms_worst,
                        "probe_sweep_ms_same_allocation": rep.ms_same_allocation}
+        if rep.candidates > 0 and rep.ms_same_allocation > 0:
+            # did the search see the other kind?  (a chosen pair within 1 % of a pair inside ONE allocation: it did not -- the storage is
+            # then as slow as an unplaced one, and the line that reports it says so)
+            self.report["both_kinds_seen"] = bool(rep.ms_chosen < 0.99 * rep.ms_same_allocation)
         self.__cuda_array_interface__ = {"shape": (self.nelem,), "typestr": "<f8", "data": (self.ptr, False), "version": 2}
 
     def __del__(self):
