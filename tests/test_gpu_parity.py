@@ -1305,6 +1305,47 @@ STENCIL = [v]
     check(bl.apply_script(mm, A, B, brick_range=None, ids=ids_dev, constants={"coeff": coeff}), "compiled", "k_expr_jit<1,s7,list>", want)
 
 
+@pytest.mark.parametrize("case", ["cond", "star2", "star4", "limiter", "mixed1"])
+def test_compiled_forms_over_irregular_lists(dev, case):
+    """the tuned kernels a program is compiled into share halos between the waves of a workgroup WHEN consecutive list entries are
+    i-neighbours; a shuffled list with skipped entries, a list running against i, and a twisted adjacency table (bricks whose -i / +i
+    links do not match) take their fallback paths -- same bits as the interpreter, which works brick by brick"""
+    from bricklib_amd.order import LIST_SKIP
+    from bricklib_amd.spec import load_spec
+    scripts = dict(EXPR_SCRIPTS, mixed1=EXPR_HEAD + """
+hi = Func("max", 2)
+u = Grid("u", 3); v = Grid("v", 3)
+uxy = u(i + 1, j + 1, k) - u(i + 1, j - 1, k) - u(i - 1, j + 1, k) + u(i - 1, j - 1, k)
+v(i, j, k).assign(u(i, j, k) + 0.25 * hi(uxy, u(i, j - 1, k + 1)) * If(uxy > 0, 1.0, 0.5))
+STENCIL = [v]
+""")
+    spec = load_spec(scripts[case])
+    consts = {"coeff": [0.1 * q - 0.25 for q in range(7)], "cfl": 0.3}
+    shape = (11, 6, 5)
+    grid, info = bl.init_grid(shape, dev)
+    g3 = grid.reshape(5, 6, 11)
+    inner = np.ascontiguousarray(g3[1:-1, 1:-1, 1:-1]).reshape(-1)
+    rng = np.random.default_rng(9)
+    shuffled = rng.permutation(inner).astype(np.uint32)
+    shuffled[::7] = LIST_SKIP
+    backwards = inner[::-1].copy()
+    # a twisted table: two bricks swap their +i neighbours (the links between list neighbours no longer hold there)
+    adj = info.adj_host.copy()
+    a, b = int(g3[2, 2, 3]), int(g3[2, 3, 3])
+    adj[a, 14], adj[b, 14] = adj[b, 14], adj[a, 14]
+    twisted = bl.BrickInfo(adj, dev)
+    st = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    st.dat.uniform_(-0.5, 0.5)
+    ck = bl.CompiledExpr(spec, consts)
+    for binfo, lst in ((info, shuffled), (info, backwards), (twisted, inner), (twisted, shuffled)):
+        s1, s2 = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(2))
+        ids = grid_to_device(lst, dev)
+        bl.apply_expr(spec, bl.Brick(binfo, st, 0), bl.Brick(binfo, s1, 0), ids=ids, constants=consts, interpret=True)
+        ck.apply(bl.Brick(binfo, st, 0), bl.Brick(binfo, s2, 0), ids=ids)
+        assert torch.equal(s1.dat, s2.dat) and s1.dat.abs().max().item() > 0.1
+    ck.release()
+
+
 def test_expression_argument_checks(dev):
     """a program is checked before anything is launched: unknown codes, registers out of range or read before written, taps
     outside the 125-point cube, too many operations"""
