@@ -419,8 +419,10 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   hiprtcResult r = rt->Create(&prog, src.c_str(), "k_expr_jit.hip", 6, hdr, names);
   if (r != HIPRTC_SUCCESS) return brk_fail(BRK_EHIP, "hiprtcCreateProgram: %s", rt->ErrorString(r));
   // -ffp-contract=off: a script's `a * b + c` stays two roundings, as in the interpreter and in the checker
-  const char *opts[] = {arch, "-O3", "-std=c++17", "-ffp-contract=off"};
-  r = rt->Compile(prog, 4, opts);
+  // -load-store-opt off, as in the library's own build (Makefile): LDS accesses stay ds_read_b64 / ds_write_b64 -- merged into ds_read2_b64
+  // they move half the bytes per LDS cycle on gfx950
+  const char *opts[] = {arch, "-O3", "-std=c++17", "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"};
+  r = rt->Compile(prog, 8, opts);
   if (r != HIPRTC_SUCCESS) {
     size_t ls = 0;
     rt->LogSize(prog, &ls);
