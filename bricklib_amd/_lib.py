@@ -155,6 +155,7 @@ def _load():
     L.brk_stencil_apply_expr.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.POINTER(ExprOp), C.c_uint32, C.c_uint32, vp]
     L.brk_expr_compile.argtypes = [C.POINTER(ExprOp), C.c_uint32, C.c_uint32, C.POINTER(vp)]
     L.brk_expr_apply.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, vp]
+    L.brk_expr_apply_box.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_uint32, C.c_uint32 * 3, C.c_uint32 * 3, C.c_uint32 * 3, vp]
     L.brk_expr_release.argtypes = [vp]
     L.brk_expr_source.argtypes = [C.POINTER(ExprOp), C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.brk_expr_kernel_source.argtypes = [vp]
@@ -171,7 +172,7 @@ lib = _load()
 # every symbol include/brk.h declares (tests check the library exports each of them)
 ABI_SYMBOLS = [
     "brk_last_error", "brk_abi_version", "brk_stencil_radius", "brk_stencil_ncoeff", "brk_stencil_iters",
-    "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_stencil_apply_list_kpaired", "brk_stencil_apply_box", "brk_stencil_apply_range_ex", "brk_stencil_apply_list_ex", "brk_stencil_apply_box_ex", "brk_stencil_apply_taps", "brk_stencil_apply_expr", "brk_expr_compile", "brk_expr_apply", "brk_expr_release", "brk_expr_source",
+    "brk_stencil_apply_range", "brk_stencil_apply_list", "brk_stencil_apply_list_kpaired", "brk_stencil_apply_box", "brk_stencil_apply_range_ex", "brk_stencil_apply_list_ex", "brk_stencil_apply_box_ex", "brk_stencil_apply_taps", "brk_stencil_apply_expr", "brk_expr_compile", "brk_expr_apply", "brk_expr_apply_box", "brk_expr_release", "brk_expr_source",
                "brk_expr_kernel_source", "brk_expr_kernel_from_disk", "brk_link_copy", "brk_array_to_brick",
     "brk_brick_to_array", "brk_compare_brick", "brk_init_grid", "brk_decomp_build", "brk_decomp_free",
     "brk_decomp_nbricks", "brk_decomp_grid_size", "brk_decomp_tdims", "brk_decomp_sep_pos", "brk_decomp_grid",

@@ -28,7 +28,7 @@ extern "C" const char *brk_last_error(void) { return g_err; }
 static thread_local const char *g_last_kernel = "";
 extern "C" void brki_note_kernel(const char *name) { g_last_kernel = name; }
 extern "C" const char *brk_last_kernel(void) { return g_last_kernel; }
-extern "C" int brk_abi_version(void) { return 1012; } // 1001: brk_stencil_apply_taps; 1002: BRK_MPI7_X2, BRK_7PT_X2; 1003: exchange; 1004: brk_adjacency_register; 1005: brk_stencil_apply_*_ex; 1006: brk_comm_library, brk_set_variant left the ABI; 1007: brk_storage_alloc / _free, brk_placement_probe; 1008: brk_finalize, brk_last_kernel; 1009: brk_storage_alloc_ex; 1010: brk_stencil_apply_expr; 1011: brk_expr_compile / _apply / _release / _source; 1012: brk_expr_kernel_from_disk
+extern "C" int brk_abi_version(void) { return 1013; } // 1001: brk_stencil_apply_taps; 1002: BRK_MPI7_X2, BRK_7PT_X2; 1003: exchange; 1004: brk_adjacency_register; 1005: brk_stencil_apply_*_ex; 1006: brk_comm_library, brk_set_variant left the ABI; 1007: brk_storage_alloc / _free, brk_placement_probe; 1008: brk_finalize, brk_last_kernel; 1009: brk_storage_alloc_ex; 1010: brk_stencil_apply_expr; 1011: brk_expr_compile / _apply / _release / _source; 1012: brk_expr_kernel_from_disk; 1013: brk_expr_apply_box
 
 // ---------------------------------------------------------------------------------------------- stencil facts
 extern "C" int brk_stencil_radius(int id) {

@@ -26,6 +26,15 @@ extern "C"
 #endif
 void brki_adj_unlock(void); // nullptr; BRK_OK leaves the tables' mutex taken until brki_adj_unlock (after the launch is enqueued)
 #ifdef __cplusplus
+extern "C" {
+#endif
+// brk_kernels.hip: the traversal order of a box as a device list; BRK_OK leaves the list cache's mutex taken until brki_box_list_unlock(stream)
+int brki_box_list_lock(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const uint32_t **ids_dev, uint32_t *n);
+int brki_box_list_unlock(brk_stream s);
+#ifdef __cplusplus
+}
+#endif
+#ifdef __cplusplus
 extern "C"
 #endif
 void brki_jit_finalize(void); // brk_finalize: unload the modules of brk_expr_compile

@@ -510,6 +510,23 @@ extern "C" int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj, con
   return BRK_OK;
 }
 
+// the reference's launch shape for a lexicographic grid (stencils/3axis.hip.cpp:36-39 `b = grid[tk][tj][ti]` over an interior box): the
+// box is walked in the order the built-in stencils use (one slab of j-rows per XCD, blocks of 8 rows swept over all k, i fastest)
+extern "C" int brk_expr_apply_box(const brk_expr_kernel *k, const uint32_t *adj, const double *in, double *out, size_t step, uint32_t base,
+                                  const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], brk_stream s) {
+  if (!tot || !lo || !cnt) return brk_fail(BRK_EINVAL, "null box geometry");
+  for (int a = 0; a < 3; ++a)
+    if (lo[a] + cnt[a] > tot[a]) return brk_fail(BRK_EINVAL, "box exceeds the grid on axis %d", a);
+  if ((uint64_t)base + (uint64_t)tot[0] * tot[1] * tot[2] > 0xFFFFFFFFull) return brk_fail(BRK_EINVAL, "brick ids overflow 32 bits");
+  if ((uint64_t)cnt[0] * cnt[1] * cnt[2] == 0) return k ? BRK_OK : brk_fail(BRK_EINVAL, "null kernel");
+  const uint32_t *ids = nullptr;
+  uint32_t n = 0;
+  if (int rc = brki_box_list_lock(base, tot, lo, cnt, &ids, &n)) return rc;
+  const int rc = brk_expr_apply(k, adj, in, out, step, ids, 0, n, s);
+  const int rc2 = brki_box_list_unlock(s);
+  return rc ? rc : rc2;
+}
+
 extern "C" int brk_expr_release(brk_expr_kernel *k) {
   if (!k) return BRK_OK;
   std::lock_guard<std::mutex> lock(g_jit_mutex);

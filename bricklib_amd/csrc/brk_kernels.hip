@@ -1031,6 +1031,27 @@ extern "C" int brk_stencil_apply_box_ex(int id, const uint32_t *adj, const doubl
   return BRK_OK;
 }
 
+// for brk_expr_apply_box (brk_jit.hip): the traversal order of a box as a device list (8-row blocks per XCD slab, as for the built-in
+// stencils); the cache's mutex stays taken until brki_box_list_unlock has recorded the launch that reads the list
+static BoxList *g_box_lent = nullptr;
+extern "C" int brki_box_list_lock(uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], const uint32_t **ids, uint32_t *n) {
+  g_box_mutex.lock();
+  BoxList *e = nullptr;
+  const int rc = box_list_locked(base, tot, lo, cnt, 8u, false, 0u, &e);
+  if (rc != BRK_OK) {
+    g_box_mutex.unlock();
+    return rc;
+  }
+  g_box_lent = e, *ids = e->dev, *n = e->n;
+  return BRK_OK;
+}
+extern "C" int brki_box_list_unlock(brk_stream s) {
+  const hipError_t e = g_box_lent ? hipEventRecord(g_box_lent->last_use, static_cast<hipStream_t>(s)) : hipSuccess;
+  g_box_lent = nullptr;
+  g_box_mutex.unlock();
+  return e == hipSuccess ? BRK_OK : brk_fail(BRK_EHIP, "hipEventRecord: %s", hipGetErrorString(e));
+}
+
 extern "C" int brk_link_copy(const brk_link *links, uint32_t n, uint64_t max_bytes, brk_stream s) {
   if (n == 0 || max_bytes == 0) return BRK_OK;
   if (!links) return brk_fail(BRK_EINVAL, "null link table");

@@ -89,9 +89,13 @@ class CompiledExpr:
         """True when the code object came out of BRK_JIT_CACHE_DIR instead of the compiler"""
         return bool(lib.brk_expr_kernel_from_disk(self._h))
 
-    def apply(self, bIn, bOut, ids=None, brick_range=None, stream=None):
+    def apply(self, bIn, bOut, ids=None, brick_range=None, box=None, stream=None):
         adj = bIn.bInfo.adj
-        if ids is not None:
+        if box is not None:      # (base, tot[3], lo[3], cnt[3]) of a lexicographic numbering, as for apply_stencil
+            base, tot, lo, cnt = box
+            u3 = lambda v: (C.c_uint32 * 3)(*[int(x) for x in v])
+            check(lib.brk_expr_apply_box(self._h, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, int(base), u3(tot), u3(lo), u3(cnt), _stream(stream)))
+        elif ids is not None:
             check(lib.brk_expr_apply(self._h, _ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, _ptr(ids), 0, ids.numel(), _stream(stream)))
         else:
             b0, b1 = brick_range if brick_range is not None else (0, bIn.bInfo.nbricks)
@@ -121,7 +125,7 @@ def expr_source(spec, constants=None):
     return buf.value.decode()
 
 
-def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None, interpret=False):
+def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None, interpret=False, box=None):
     """A stencil script as an expression: `spec` = bricklib_amd.spec.load_spec(...) of ANY script up to radius 4 -- Func("max" / "min" /
     "abs" / "sqrt"), comparisons, If, products of grid references included (what the reference's generator accepts; stencils/cond.py is
     made of these).  constants: values of the script's ConstRef names.
@@ -138,12 +142,14 @@ def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stre
         if ck is None or not ck._h:
             ck = cache[key] = CompiledExpr(spec, constants)
         try:
-            return ck.apply(bIn, bOut, ids=ids, brick_range=brick_range, stream=stream)
+            return ck.apply(bIn, bOut, ids=ids, brick_range=brick_range, box=box, stream=stream)
         except BrkError as e:
             if "compile the program again" not in str(e):
                 raise
         ck = cache[key] = CompiledExpr(spec, constants)       # unloaded by finalize(): the same kernel, loaded again
-        return ck.apply(bIn, bOut, ids=ids, brick_range=brick_range, stream=stream)
+        return ck.apply(bIn, bOut, ids=ids, brick_range=brick_range, box=box, stream=stream)
+    if box is not None:
+        raise ValueError("the interpreter takes brick lists and ranges; box= needs the compiled form")
     tab, n, result = _expr_table(spec, constants)
     adj = bIn.bInfo.adj
     if ids is not None:

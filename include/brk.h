@@ -67,7 +67,8 @@ const char *brk_last_error(void);
  * brk_set_variant is no longer part of the ABI; 1007: brk_storage_alloc / brk_storage_free / brk_placement_probe;
  * 1008: brk_finalize, brk_last_kernel; 1009: brk_storage_alloc_ex; 1010: brk_stencil_apply_expr;
  * 1011: brk_expr_compile / brk_expr_apply / brk_expr_release / brk_expr_source / brk_expr_kernel_source;
- * 1012: brk_expr_kernel_from_disk (BRK_JIT_CACHE_DIR)) */
+ * 1012: brk_expr_kernel_from_disk (BRK_JIT_CACHE_DIR);
+ * 1013: brk_expr_apply_box) */
 int brk_abi_version(void);
 /* Orderly end of the library's use of the GPU before a process leaves main(): waits for everything enqueued on the current device
  * and releases, on the CALLING thread, what the library itself holds there (box id lists and their events, derived tables of
@@ -202,6 +203,10 @@ typedef struct brk_expr_kernel brk_expr_kernel;
 int brk_expr_compile(const brk_expr_op *ops_host, uint32_t nops, uint32_t result_reg, brk_expr_kernel **out);
 int brk_expr_apply(const brk_expr_kernel *k, const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
                    const uint32_t *brick_ids_dev /* or NULL */, uint32_t first, uint32_t n, brk_stream s);
+/* ... over the interior box of a lexicographic numbering (ABI 1013; geometry as for brk_stencil_apply_box: ids base + (k * tot[1] + j) *
+ * tot[0] + i for (i, j, k) in [lo, lo + cnt)), walked in the built-in stencils' order -- no id list to build */
+int brk_expr_apply_box(const brk_expr_kernel *k, const uint32_t *adj_dev, const double *in_dev, double *out_dev, size_t step_elems,
+                       uint32_t base, const uint32_t tot[3], const uint32_t lo[3], const uint32_t cnt[3], brk_stream s);
 int brk_expr_release(brk_expr_kernel *k);
 /* the generated translation unit: of a program (buf may be NULL; *need = bytes incl. the terminator) / of a compiled kernel */
 int brk_expr_source(const brk_expr_op *ops_host, uint32_t nops, uint32_t result_reg, char *buf, size_t cap, size_t *need);

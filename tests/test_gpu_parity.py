@@ -1346,6 +1346,40 @@ STENCIL = [v]
     ck.release()
 
 
+@pytest.mark.parametrize("case", ["cond", "star2", "limiter", "far3"])
+def test_compiled_expression_over_a_box(dev, case):
+    """brk_expr_apply_box: the reference's launch shape (interior box of an init_grid numbering) for a compiled script -- the box is
+    walked in the built-in stencils' order, no id list to build; same bits as the list form over the same bricks, nothing outside the
+    box is written, geometry errors are refused"""
+    from bricklib_amd._lib import BrkError
+    from bricklib_amd.spec import load_spec
+    spec = load_spec(EXPR_SCRIPTS[case])
+    consts = {"coeff": [0.1 * q - 0.25 for q in range(7)], "cfl": 0.3}
+    ck = bl.CompiledExpr(spec, consts)
+    for shape in ((10, 10, 10), (7, 21, 5), (66, 13, 4)):
+        ni, nj, nk = shape
+        grid, info = bl.init_grid(shape, dev)
+        st, s1, s2 = (bl.BrickStorage.allocate(info.nbricks, 512, dev) for _ in range(3))
+        st.dat.uniform_(-0.5, 0.5)
+        box = (0, shape, (1, 1, 1), (ni - 2, nj - 2, nk - 2))
+        ck.apply(bl.Brick(info, st, 0), bl.Brick(info, s1, 0), box=box)
+        ids = np.ascontiguousarray(grid.reshape(nk, nj, ni)[1:-1, 1:-1, 1:-1]).reshape(-1)
+        ck.apply(bl.Brick(info, st, 0), bl.Brick(info, s2, 0), ids=grid_to_device(ids, dev))
+        assert torch.equal(s1.dat, s2.dat) and s1.dat.abs().max().item() > 0.1
+        mask = torch.ones(info.nbricks, dtype=torch.bool, device=dev)
+        mask[torch.from_numpy(ids.astype(np.int64)).to(dev)] = False
+        assert (s1.dat.view(-1, 512)[mask] == 0).all()
+        ck.apply(bl.Brick(info, st, 0), bl.Brick(info, s1, 0), box=(0, shape, (1, 1, 1), (ni - 2, 0, nk - 2)))     # empty box
+        with pytest.raises(BrkError):
+            ck.apply(bl.Brick(info, st, 0), bl.Brick(info, s1, 0), box=(0, shape, (1, 1, 1), (ni, nj - 2, nk - 2)))
+    s3 = bl.BrickStorage.allocate(info.nbricks, 512, dev)
+    bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, s3, 0), box=box, constants=consts)      # the one-call form
+    assert torch.equal(s3.dat, s1.dat)
+    with pytest.raises(ValueError):
+        bl.apply_expr(spec, bl.Brick(info, st, 0), bl.Brick(info, s3, 0), box=box, constants=consts, interpret=True)
+    ck.release()
+
+
 def test_expression_argument_checks(dev):
     """a program is checked before anything is launched: unknown codes, registers out of range or read before written, taps
     outside the 125-point cube, too many operations"""

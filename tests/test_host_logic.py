@@ -20,7 +20,7 @@ def test_abi_symbols_exported():
     L = C.CDLL(LIB_PATH)
     for s in ABI_SYMBOLS:
         assert hasattr(L, s), s
-    assert lib.brk_abi_version() == 1012
+    assert lib.brk_abi_version() == 1013
     # development knobs stay out of the product library (they exist in `make DEV=1` / `VARIANTS=1` builds only)
     if os.environ.get("BRK_DEV_BUILD") != "1":
         for s in ("brk_set_variant", "brk_debug_pad_lds", "brk_debug_diag", "brk_debug_stamps"):
