@@ -58,6 +58,16 @@ int main() {
   }
   gpuCheck(hipMemcpy(got_c.data(), dout, elems * 8, hipMemcpyDeviceToHost));
   printf("compiled kernel: %s\n", brk_last_kernel());
+  // the same bricks as the reference's launch shape: the interior box of the lexicographic grid, no id list
+  std::vector<double> got_b(elems);
+  gpuCheck(hipMemset(dout, 0, elems * 8));
+  const uint32_t tot[3] = {NB, NB, NB}, lo[3] = {1, 1, 1}, cnt[3] = {NB - 2, NB - 2, NB - 2};
+  if (brk_expr_apply_box(kernel, dadj, din, dout, 512, 0, tot, lo, cnt, nullptr) != BRK_OK) {
+    printf("brk_expr_apply_box: %s\n", brk_last_error());
+    return 1;
+  }
+  gpuCheck(hipMemcpy(got_b.data(), dout, elems * 8, hipMemcpyDeviceToHost));
+  printf("box form == list form: %s\n", got_b == got_c ? "yes" : "NO");
 
   // CPU loop over the same cells through the accessor semantics (neighbour brick = adjacency entry)
   auto at = [&](unsigned b, int k, int j, int i) {
@@ -82,5 +92,5 @@ int main() {
   free(info.adj);
   free(grid);
   brk_finalize();
-  return same_i && same_c ? 0 : 1;
+  return same_i && same_c && got_b == got_c ? 0 : 1;
 }

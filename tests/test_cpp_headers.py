@@ -274,6 +274,7 @@ def test_cpp_host_runs_a_stencil_given_as_data():
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
     assert "interpreted (brk_stencil_apply_expr): result match" in out and "compiled at run time (brk_expr_compile): result match" in out, out
+    assert "box form == list form: yes" in out, out
     assert "compiled kernel: k_expr_jit<2,star_wg>" in out, out      # every tap on one axis, radius 2: the star kernel's cell update
 
 
