@@ -159,13 +159,14 @@ def apply_expr(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stre
         check(lib.brk_stencil_apply_expr(_ptr(adj), _ptr(bIn.dat), _ptr(bOut.dat), bIn.step, None, int(b0), int(b1 - b0), tab, n, result, _stream(stream)))
 
 
-def apply_script(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None):
+def apply_script(spec, bIn, bOut, ids=None, brick_range=None, constants=None, stream=None, box=None):
     """A stencil script, whatever it is -- the front end's dispatch.  Returns the path taken:
       "builtin:<name>"  the script is one of the reference's stencils (same offsets, same coefficient expressions, the MPI_* constants at
                         their fake.h values): its tuned kernel;
       "compiled"        non-linear scripts, and linear ones of up to 40 taps: compiled at run time on first use (star-shaped ones into the
                         tuned star kernels), apply_expr;
-      "taps"            linear scripts with more taps: the tap tables, apply_taps."""
+      "taps"            linear scripts with more taps: the tap tables, apply_taps (brick lists and ranges only).
+    box=(base, tot[3], lo[3], cnt[3]): the interior box of a lexicographic numbering instead of ids / brick_range, as for apply_stencil."""
     from .spec import MPI_DEFAULTS
     consts = dict(MPI_DEFAULTS)
     consts.update(constants or {})
@@ -174,15 +175,17 @@ def apply_script(spec, bIn, bOut, ids=None, brick_range=None, constants=None, st
         coeff = np.zeros(129)
         c = np.asarray(consts["coeff"], dtype=np.float64)
         coeff[:min(c.size, 129)] = c[:129]
-        apply_stencil("7pt", bIn, bOut, ids=ids, brick_range=brick_range, coeff=coeff, stream=stream)
+        apply_stencil("7pt", bIn, bOut, ids=ids, brick_range=brick_range, box=box, coeff=coeff, stream=stream)
         return "builtin:7pt"
     if name and name.startswith("mpi") and all(consts[k] == v for k, v in MPI_DEFAULTS.items()):
-        apply_stencil(name, bIn, bOut, ids=ids, brick_range=brick_range, stream=stream)
+        apply_stencil(name, bIn, bOut, ids=ids, brick_range=brick_range, box=box, stream=stream)
         return "builtin:" + name
     if spec.linear and len(spec.offsets) > 40:
+        if box is not None:
+            raise ValueError("the tap tables take brick lists and ranges (bricklib_amd.order.tiled builds the list of a box)")
         apply_taps(spec.taps(consts), bIn, bOut, ids=ids, brick_range=brick_range, stream=stream)
         return "taps"
-    apply_expr(spec, bIn, bOut, ids=ids, brick_range=brick_range, constants=consts, stream=stream)
+    apply_expr(spec, bIn, bOut, ids=ids, brick_range=brick_range, constants=consts, stream=stream, box=box)
     return "compiled"
 
 

@@ -1303,6 +1303,14 @@ STENCIL = [v]
     want = np.zeros_like(hin)
     oracle.brick_expr(mm, info.adj_host, hin, want, 512, ids, {"coeff": coeff})
     check(bl.apply_script(mm, A, B, brick_range=None, ids=ids_dev, constants={"coeff": coeff}), "compiled", "k_expr_jit<1,s7,list>", want)
+    # the box form: the tuned box kernels for a built-in, brk_expr_apply_box for a compiled script
+    box = (0, (6, 6, 6), (1, 1, 1), (4, 4, 4))
+    check(bl.apply_script(mm, A, B, box=box, constants={"coeff": coeff}), "compiled", "k_expr_jit<1,s7,list>", want)
+    want = np.zeros_like(hin)
+    oracle.brick_stencil(ST_7PT_COEFF, info.adj_host, hin, want, 512, ids=ids, coeff=coeff)
+    check(bl.apply_script(seven, A, B, box=box, constants={"coeff": coeff}), "builtin:7pt", "k_s7_wg<kCoeff,8,kModeBox>", want)
+    with pytest.raises(ValueError):
+        bl.apply_script(blur, A, B, box=box, constants={"coeff": coeff})
 
 
 @pytest.mark.parametrize("case", ["cond", "star2", "star4", "limiter", "mixed1"])
