@@ -436,6 +436,13 @@ extern "C" int brk_expr_compile(const brk_expr_op *ops, uint32_t nops, uint32_t 
   std::string code(cs, '\0');
   rt->Code(prog, &code[0]);
   rt->Destroy(&prog);
+  { // the kernels are looked up by their (Itanium) names further down: a drift between those and the headers shows here, GPU or not
+    const bool star = star_shaped(ops, nops);
+    const char *want[2] = {star && R == 1 ? kS7List : (star ? (R == 2 ? kSw2 : kSw4) : (cube_form(ops, nops, R) ? (R == 1 ? kCube1 : kCube2) : "k_expr_jit")),
+                           star && R == 1 ? kS7Range : nullptr};
+    for (const char *w : want)
+      if (w && code.find(w) == std::string::npos) return brk_fail(BRK_EHIP, "the compiled unit does not define %s (brk_jit.hip and the kernel headers disagree)", w);
+  }
   if (!have_device) return brk_fail(BRK_ENODEV, "the program compiled for %s (%zu bytes of code) but there is no device to load it on", arch + 15, cs);
   if (!disk.empty()) { // best effort, atomically: a reader never sees half a file
     const std::string tmp = disk + "." + std::to_string((unsigned long long)getpid());

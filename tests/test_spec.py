@@ -229,7 +229,10 @@ def test_expression_source_generation_and_compilation_without_a_device():
     assert "template __global__ void k_s7_wg<kUser, 8, kModeList>(" in seven and "r0 = kp;" in seven
     if torch.cuda.is_available():
         return
-    for sp, consts in ((s, {"lim": 0.75}), (load_spec(COND_LIKE), {"coeff": [0.1] * 7})):
+    # every form of generated unit compiles here and defines the kernel its launcher will ask for by name (checked before the device is):
+    # star radius 2 (k_star_wg), star radius 1 (k_s7_wg, list + range), star radius 4, off-axis radius 1 / 2 (k_cube_dense), radius 3 (plain tile)
+    off = lambda a, b: load_spec(PRELUDE + NONLINEAR[1].replace("g(i + 1, j, k)", "g(i + %d, j - %d, k)" % (a, b)))
+    for sp, consts in ((s, {"lim": 0.75}), (load_spec(COND_LIKE), {"coeff": [0.1] * 7}), (off(4, 0), None), (off(1, 1), None), (off(1, 2), None), (off(3, 2), None)):
         with pytest.raises(BrkError, match="compiled for gfx950 .* no device|libhiprtc"):
             CompiledExpr(sp, consts)
 
