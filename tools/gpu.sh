@@ -7,6 +7,8 @@
 #   evidence <tag>                  end-of-round evidence: default bench line, kernel-trace stats and PMC passes of the same command
 #                                   -> gpurun_out/<tag>/ (bench_default.json, kernel_stats.csv, pmc_summary.txt, pmc_traffic_all.json, ...)
 #   strong                          strong tests + `bench.py --workload strong` with local ghosts aliased / copied + weak 25-pt cycle
+#   expr                            stencils given as data: the GPU tests of the tap / expression paths, then tools/expr_bench.py (ms per sweep of
+#                                   every form: tuned kernel, tap tables, interpreter, compiled at run time) -> gpurun_out/r05_expr.txt
 #   kbench <kbench args>            tools/kbench with the arguments given
 #   occ7 | occall | order7 | reg7   kernel experiments with the default library (occupancy padding, traversal order, registered adjacency)
 #   diag7 | reg7d | abl | prio      the same with a diagnostic build (make -C bricklib_amd/csrc EXTRA_HIPFLAGS=-DBRK_DIAG before gpurun)
